@@ -1,0 +1,527 @@
+"""CPU ORACLE — test infrastructure only.  NOT part of the product path.
+
+A from-scratch CPU (torch/numpy fp64) restatement of the reference's algorithm for the
+hot path named in BASELINE.json (pulser_diff.backend.TorchEmulator inner propagator loop).
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module; the product (``pulser-diff_amd/``) never does.
+
+Parity status: PINNED by the stored outputs of the reference's own tutorial notebook
+(tests/golden/notebook_pins.json, transcribed by tests/golden/extract_notebook_pins.py):
+KA-1 (DP5_SE, 160-point <sum Z>(t), printed amplitudes), KA-2..4 (KRYLOV_SE final <sum Z>),
+KA-5 (Adam loss traces = gradient pins).  The reference itself cannot be imported here
+(pyqtorch / pulser / pulser_simulation / qutip are absent; ordinary missing modules, no
+permission denial) and its tests hold no static vectors.
+
+Third-party owners of arithmetic that are NOT under /root/reference and are restated from
+their published behaviour: ``pyqtorch`` (unpinned, pyproject.toml:31) for sesolve
+(KRYLOV_SE / DP5_SE) and ``pulser-core`` @ fcf980463f47 for waveform sampling
+(Blackman / Ramp / Constant / Custom) and MockDevice's C6.
+
+Each function cites the reference file:line it follows (paths under /root/reference).
+"""
+from __future__ import annotations
+
+import itertools
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Sequence
+
+import numpy as np
+import torch
+from torch import Tensor
+
+# pulser MockDevice, rydberg_level=70: interaction_coeff C6/hbar in rad/us * um^6
+# (used at pulser_diff/hamiltonian.py:343 via self._device.interaction_coeff).
+C6_MOCK_DEVICE = 5420158.53
+
+CDTYPE = torch.complex128
+RDTYPE = torch.float64
+
+
+# --------------------------------------------------------------------------------------
+# Waveform samplers (pulser.waveforms restated; pinned by KA-1..KA-5)
+# --------------------------------------------------------------------------------------
+def blackman_waveform(duration: int, area) -> Tensor:
+    """pulser BlackmanWaveform: clip(np.blackman(d), 0) * area / sum / 1e-3 (rad/us)."""
+    win = torch.as_tensor(np.clip(np.blackman(int(duration)), 0.0, np.inf), dtype=RDTYPE)
+    area = torch.as_tensor(area).to(RDTYPE)
+    return win * (area / (win.sum() * 1e-3))
+
+
+def ramp_waveform(duration: int, start, stop) -> Tensor:
+    """pulser RampWaveform: start + (stop-start) * k/(d-1)."""
+    start = torch.as_tensor(start).to(RDTYPE)
+    stop = torch.as_tensor(stop).to(RDTYPE)
+    k = torch.arange(int(duration), dtype=RDTYPE)
+    return start + (stop - start) * k / (int(duration) - 1)
+
+
+def constant_waveform(duration: int, value) -> Tensor:
+    value = torch.as_tensor(value).to(RDTYPE)
+    return value * torch.ones(int(duration), dtype=RDTYPE)
+
+
+def custom_waveform(samples) -> Tensor:
+    return torch.as_tensor(samples).to(RDTYPE)
+
+
+@dataclass
+class SampledGlobalSequence:
+    """Per-ns samples of ONE global ground-rydberg channel, extended by one trailing sample.
+
+    Follows pulser sampler.sample + TorchEmulator.__init__ (pulser_diff/backend.py:113-115):
+    ``samples_obj = sampled_seq.extend_duration(tot_duration + 1)`` (amp/det padded with 0).
+    """
+
+    amp: Tensor  # (T_ns + 1,)
+    det: Tensor
+    phase: Tensor
+
+    @property
+    def tot_duration(self) -> int:  # backend.py:114
+        return int(self.amp.shape[0]) - 1
+
+
+def concat_pulses(pulses: Sequence[tuple[Tensor, Tensor, Tensor | float]]) -> SampledGlobalSequence:
+    """Concatenate (amp, det, phase) pulses on one channel and pad one trailing sample."""
+    amps, dets, phases = [], [], []
+    for amp, det, phase in pulses:
+        amp = torch.as_tensor(amp).to(RDTYPE)
+        det = torch.as_tensor(det).to(RDTYPE)
+        ph = torch.as_tensor(phase).to(RDTYPE)
+        if ph.ndim == 0 or ph.numel() == 1:
+            ph = ph.reshape(()) * torch.ones_like(amp)
+        amps.append(amp)
+        dets.append(det)
+        phases.append(ph)
+    zero = torch.zeros(1, dtype=RDTYPE)
+    amp = torch.cat(amps + [zero])
+    det = torch.cat(dets + [zero])
+    phase = torch.cat(phases + [phases[-1][-1:].detach()])
+    return SampledGlobalSequence(amp, det, phase)
+
+
+# --------------------------------------------------------------------------------------
+# Sampling grid (pulser_diff/hamiltonian.py:69-73, 83-91) and evaluation times
+# (pulser_diff/backend.py:312-375)
+# --------------------------------------------------------------------------------------
+def adapt_to_sampling_rate(full_array: Tensor, sampling_rate: float, duration: int) -> Tensor:
+    """hamiltonian.py:83-91 — truncating integer index grid (irregular spacing for rate<1)."""
+    indices = torch.linspace(0, len(full_array) - 1, int(sampling_rate * duration), dtype=torch.int)
+    return full_array[indices.long()]
+
+
+def sampling_times(tot_duration: int, sampling_rate: float) -> Tensor:
+    """hamiltonian.py:68-73 with _duration = samples_obj.max_duration = tot_duration + 1."""
+    duration = tot_duration + 1
+    return adapt_to_sampling_rate(torch.arange(duration, dtype=RDTYPE) / 1000, sampling_rate, duration)
+
+
+def evaluation_times(tot_duration: int, sampling_rate: float, value="Full") -> Tensor:
+    """backend.py:312-375."""
+    st = sampling_times(tot_duration, sampling_rate)
+    if isinstance(value, str):
+        if value == "Full":
+            ev = st.clone()
+        elif value == "Minimal":
+            ev = torch.tensor([], dtype=RDTYPE)
+        else:
+            raise ValueError("Wrong evaluation time label.")
+    elif isinstance(value, float):
+        if value > 1 or value <= 0:
+            raise ValueError("evaluation_times float must be between 0 and 1.")
+        idx = torch.linspace(0, len(st) - 1, int(value * len(st)), dtype=torch.int)
+        ev = st[idx.long()]
+    else:
+        ev = torch.as_tensor(value, dtype=RDTYPE)
+        if ev.max() > tot_duration / 1000:
+            raise ValueError("Provided evaluation-time list extends further than sequence duration.")
+        if ev.min() < 0:
+            raise ValueError("Provided evaluation-time list contains negative values.")
+    return torch.cat([ev, torch.tensor([0.0, tot_duration / 1000], dtype=ev.dtype)]).unique()
+
+
+# --------------------------------------------------------------------------------------
+# Hamiltonian pieces (pulser_diff/hamiltonian.py:288-318, 333-344, 406-454, 499-548)
+# --------------------------------------------------------------------------------------
+def pair_distances(coords: Tensor) -> list[Tensor]:
+    """hamiltonian.py:341 — dist = ||q1 - q2|| for itertools.combinations order."""
+    n = coords.shape[0]
+    return [torch.linalg.norm(coords[i] - coords[j]) for i, j in itertools.combinations(range(n), 2)]
+
+
+def interaction_strengths(coords: Tensor, c6: float = C6_MOCK_DEVICE) -> Tensor:
+    """U_ij = C6 / r_ij^6 (net of hamiltonian.py:343 `0.5*C6/dist**6` and :536 `2*int_mat`)."""
+    d = torch.stack(pair_distances(torch.as_tensor(coords, dtype=RDTYPE)))
+    return c6 / d**6
+
+
+@dataclass
+class HamTerms:
+    """What `_construct_hamiltonian` hands to `build_ham_tensor` for a global g-r channel.
+
+    amp_coeff = adapt(0.5*amp*exp(-1j*phase))   (hamiltonian.py:420-421, 432)  or None if all zero (:425)
+    det_coeff = adapt(-0.5*det)                 (hamiltonian.py:422, 432)      or None if all zero
+    """
+
+    n_qubits: int
+    u_pairs: Tensor  # (N(N-1)/2,) real, order itertools.combinations
+    amp_coeff: Tensor | None  # complex (n,)
+    det_coeff: Tensor | None  # real (n,)
+    dt: float  # 0.001 / sampling_rate (hamiltonian.py:523)
+    n_samples: int  # hamiltonian.py:524
+    amp_targets: list[int] = field(default_factory=list)  # qubits driven (global => all)
+    det_targets: list[int] = field(default_factory=list)
+
+
+def build_terms(seq: SampledGlobalSequence, coords: Tensor, sampling_rate: float,
+                c6: float = C6_MOCK_DEVICE, u_pairs: Tensor | None = None) -> HamTerms:
+    n_q = int(coords.shape[0])
+    duration = seq.tot_duration + 1
+    amp_c = 0.5 * seq.amp * torch.exp(-1j * seq.phase.to(CDTYPE))
+    det_c = -0.5 * seq.det
+    amp_coeff = adapt_to_sampling_rate(amp_c, sampling_rate, duration) if bool(torch.any(amp_c != 0)) else None
+    det_coeff = adapt_to_sampling_rate(det_c, sampling_rate, duration) if bool(torch.any(det_c != 0)) else None
+    n_samples = int(sampling_rate * duration)
+    if u_pairs is None:
+        u_pairs = interaction_strengths(coords, c6) if n_q > 1 else torch.zeros(0, dtype=RDTYPE)
+    return HamTerms(n_q, u_pairs, amp_coeff, det_coeff, 0.001 / sampling_rate, n_samples,
+                    list(range(n_q)), list(range(n_q)))
+
+
+def interp_indices(t: float, dt: float, n_samples: int) -> tuple[int, int]:
+    """hamiltonian.py:532-533."""
+    i1 = max(int(min(math.floor(t / dt), n_samples - 2)), 0)
+    i2 = min(i1 + 1, n_samples - 2)
+    return i1, i2
+
+
+def interp_coeff(c: Tensor, t, dt: float, n_samples: int) -> Tensor:
+    """hamiltonian.py:538 / :542 — linear interpolation of the (complex) coefficient."""
+    tf = float(t)
+    i1, i2 = interp_indices(tf, dt, n_samples)
+    return c[i1] + (c[i2] - c[i1]) * (t - i1 * dt) / dt
+
+
+def _bit(x: np.ndarray, n: int, j: int) -> np.ndarray:
+    """basis: qubit 0 is the most-significant bit; r=0, g=1 (hamiltonian.py:299, utils.py:127-129)."""
+    return (x >> (n - 1 - j)) & 1
+
+
+def occupation_table(n: int) -> Tensor:
+    """n_j(x) = 1 - bit_j(x): projector |r><r| occupation, shape (N, 2^N)."""
+    x = np.arange(2**n)
+    return torch.as_tensor(np.stack([1 - _bit(x, n, j) for j in range(n)]), dtype=RDTYPE)
+
+
+def interaction_diagonal(n: int, u_pairs: Tensor) -> Tensor:
+    """sum_{i<j} U_ij n_i n_j as a (2^N,) vector; differentiable in u_pairs."""
+    occ = occupation_table(n)
+    diag = torch.zeros(2**n, dtype=RDTYPE)
+    for k, (i, j) in enumerate(itertools.combinations(range(n), 2)):
+        diag = diag + u_pairs[k] * occ[i] * occ[j]
+    return diag
+
+
+def dense_hamiltonian(terms: HamTerms, t) -> Tensor:
+    """Dense H(t) from the structured form:
+
+    (H psi)[x] = [sum U_ij n_i n_j - sum_j delta_j(t) n_j] psi[x]
+                 + sum_j c_j(t) psi[x^m_j]        if bit_j(x) = 1   (row g: <g|H|r> = c)
+                 + sum_j conj(c_j(t)) psi[x^m_j]  if bit_j(x) = 0
+    with c = 0.5*amp*exp(-i*phase) interpolated as a complex number and the `+adjoint`
+    doubling of the -0.5*det diagonal (hamiltonian.py:536-544).
+    """
+    n = terms.n_qubits
+    dim = 2**n
+    occ = occupation_table(n)
+    diag = interaction_diagonal(n, terms.u_pairs).to(CDTYPE)
+    ham = torch.diag(diag)
+    if terms.det_coeff is not None:
+        d = interp_coeff(terms.det_coeff, t, terms.dt, terms.n_samples)  # = -0.5*det(t)
+        for j in terms.det_targets:
+            ham = ham + torch.diag((2.0 * d * occ[j]).to(CDTYPE))
+    if terms.amp_coeff is not None:
+        c = interp_coeff(terms.amp_coeff, t, terms.dt, terms.n_samples)
+        x = np.arange(dim)
+        for j in terms.amp_targets:
+            m = 1 << (n - 1 - j)
+            rows_g = torch.as_tensor(x[(x & m) != 0])
+            lower = torch.zeros(dim, dim, dtype=CDTYPE)
+            lower[rows_g, rows_g ^ m] = 1.0  # |g><r| on qubit j
+            ham = ham + c * lower + torch.conj(c) * lower.T
+    return ham
+
+
+# ---- literal restatement of the reference's sparse-COO assembly (used to cross-check the
+# ---- structured form above, and as the CPU-baseline workload: H is rebuilt on every call)
+def _sparse_kron(mats: list[Tensor]) -> Tensor:
+    """utils.py:12-44 semantics (Kronecker product of sparse factors), via dense-free index math."""
+    out = mats[0].coalesce()
+    for m in mats[1:]:
+        m = m.coalesce()
+        ia, va = out.indices(), out.values()
+        ib, vb = m.indices(), m.values()
+        rows = (ia[0][:, None] * m.shape[0] + ib[0][None, :]).reshape(-1)
+        cols = (ia[1][:, None] * m.shape[1] + ib[1][None, :]).reshape(-1)
+        vals = (va[:, None] * vb[None, :]).reshape(-1)
+        out = torch.sparse_coo_tensor(torch.stack([rows, cols]), vals,
+                                      (out.shape[0] * m.shape[0], out.shape[1] * m.shape[1])).coalesce()
+    return out
+
+
+def reference_style_operators(terms: HamTerms):
+    """hamiltonian.py:288-318 (basis r=0,g=1; sigma_ab = |a><b|), :221-268 (build_operator),
+    :368-404 (interaction term with U = 0.5*C6/r^6)."""
+    n = terms.n_qubits
+    eye = torch.eye(2, dtype=CDTYPE).to_sparse()
+    ket = {"r": torch.tensor([[1.0], [0.0]], dtype=CDTYPE), "g": torch.tensor([[0.0], [1.0]], dtype=CDTYPE)}
+    op = {"sigma_" + p: (ket[p[0]] @ ket[p[1]].mH).to_sparse() for p in ("gr", "rr", "gg")}
+
+    def build(opname: str, qubits: list[int]) -> Tensor:
+        lst = [eye] * n
+        for q in qubits:
+            lst = lst[:q] + [op[opname]] + lst[q + 1:]
+        return _sparse_kron(lst)
+
+    dim = 2**n
+    int_mat = torch.sparse_coo_tensor(torch.zeros(2, 1, dtype=torch.long), torch.zeros(1, dtype=CDTYPE), (dim, dim))
+    for k, (i, j) in enumerate(itertools.combinations(range(n), 2)):
+        int_mat = int_mat + build("sigma_rr", [i, j]) * (0.5 * terms.u_pairs[k]).to(CDTYPE)
+    amp_mat = det_mat = None
+    if terms.amp_coeff is not None:
+        amp_mat = sum((build("sigma_gr", [q]) for q in terms.amp_targets[1:]), build("sigma_gr", [terms.amp_targets[0]]))
+    if terms.det_coeff is not None:
+        det_mat = sum((build("sigma_rr", [q]) for q in terms.det_targets[1:]), build("sigma_rr", [terms.det_targets[0]]))
+    return int_mat.coalesce(), amp_mat, det_mat
+
+
+def reference_style_H_t(terms: HamTerms) -> Callable[[float], Tensor]:
+    """hamiltonian.py:499-548: returns the closure that RE-ASSEMBLES sparse H on every call."""
+    int_mat, amp_mat, det_mat = reference_style_operators(terms)
+    dt, n_samples = terms.dt, terms.n_samples
+    det_val = (1.0 + 0.0j) * terms.det_coeff if terms.det_coeff is not None else None
+    amp_val = terms.amp_coeff
+
+    def H_t(t):
+        if not isinstance(t, Tensor):
+            t = torch.tensor(t, dtype=RDTYPE)
+        i1, i2 = interp_indices(float(t), dt, n_samples)
+        ham = 2 * int_mat
+        if det_mat is not None:
+            det = det_val[i1] + (det_val[i2] - det_val[i1]) * (t - i1 * dt) / dt
+            ham_mat = det_mat * det
+            ham = ham + ham_mat + ham_mat.adjoint()
+        if amp_mat is not None:
+            amp = amp_val[i1] + (amp_val[i2] - amp_val[i1]) * (t - i1 * dt) / dt
+            ham_mat = amp_mat * amp
+            ham = ham + ham_mat + ham_mat.adjoint()
+        return ham
+
+    return H_t
+
+
+# --------------------------------------------------------------------------------------
+# Initial state / observables (backend.py:253-280, utils.py:47-86)
+# --------------------------------------------------------------------------------------
+def all_ground_state(n: int, batch: int = 1) -> Tensor:
+    """backend.py:266-271: kron of N |g> kets = e_{dim-1}, shape (dim, B)."""
+    psi = torch.zeros(2**n, batch, dtype=CDTYPE)
+    psi[-1, :] = 1.0
+    return psi
+
+
+def total_magnetization_diag(n: int) -> Tensor:
+    """utils.py:47-65 restricted to its diagonal: sum_j Z_j, Z=diag(+1 (r), -1 (g))."""
+    occ = occupation_table(n)
+    return (2.0 * occ - 1.0).sum(0)
+
+
+def total_magnetization(n: int) -> Tensor:
+    return torch.diag(total_magnetization_diag(n).to(CDTYPE))
+
+
+def expect(obs: Tensor, states: Tensor) -> Tensor:
+    """utils.py:79-81: states (n_t, dim, B) -> einsum('...ij,jk,...kl->...')."""
+    return torch.einsum("...ij,jk,...kl->...", states.mH, obs, states)
+
+
+# --------------------------------------------------------------------------------------
+# Propagators (pyqtorch.sesolve restated; call site pulser_diff/backend.py:488-494)
+# --------------------------------------------------------------------------------------
+def krylov_map_dense(terms: HamTerms, psi0: Tensor, tsave: Tensor) -> Tensor:
+    """KRYLOV_SE semantics: psi_{k+1} = exp(-i H(t_{k+1}) (t_{k+1}-t_k)) psi_k  (right-endpoint
+    H freezing; established against KA-2..4).  Exact dense matrix exponential; differentiable."""
+    states = [psi0]
+    psi = psi0
+    for k in range(len(tsave) - 1):
+        h = dense_hamiltonian(terms, tsave[k + 1])
+        psi = torch.linalg.matrix_exp(-1j * h * (tsave[k + 1] - tsave[k])) @ psi
+        states.append(psi)
+    return torch.stack(states)
+
+
+def lanczos_expm_multiply(matvec: Callable[[np.ndarray], np.ndarray], v: np.ndarray, tau: float,
+                          max_krylov: int = 80, tol: float = 1e-12) -> np.ndarray:
+    """exp(-i*tau*H) v by Lanczos (pyqtorch KRYLOV_SE restated: <=80 vectors, small tridiagonal
+    exponential, residual-based stopping).  numpy, Hermitian H given as a matvec."""
+    nrm = np.linalg.norm(v)
+    if nrm == 0:
+        return v.copy()
+    basis = [v / nrm]
+    alphas, betas = [], []
+    w_prev = None
+    for j in range(max_krylov):
+        w = matvec(basis[j])
+        a = np.vdot(basis[j], w).real
+        w = w - a * basis[j] - (betas[-1] * basis[j - 1] if j > 0 else 0.0)
+        # full re-orthogonalisation keeps the small problem clean
+        for b in basis:
+            w = w - np.vdot(b, w) * b
+        alphas.append(a)
+        beta = np.linalg.norm(w)
+        tri = np.diag(alphas) + np.diag(betas, 1) + np.diag(betas, -1)
+        evals, evecs = np.linalg.eigh(tri)
+        coeffs = evecs @ (np.exp(-1j * tau * evals) * evecs[0].conj())
+        if beta * abs(coeffs[-1]) * abs(tau) < tol or beta < 1e-14:
+            break
+        betas.append(beta)
+        basis.append(w / beta)
+    out = np.zeros_like(v)
+    for c, b in zip(coeffs, basis):
+        out = out + c * b
+    return nrm * out
+
+
+def structured_matvec_numpy(n: int, diag: np.ndarray, c: complex, psi: np.ndarray,
+                            targets: Sequence[int] | None = None) -> np.ndarray:
+    """Matrix-free H psi for a global drive: diag*psi + sum_j [c on rows g, conj(c) on rows r] psi[x^m_j]."""
+    shape = (2,) * n + psi.shape[1:]
+    p = psi.reshape(shape)
+    out = (diag.reshape((2,) * n + (1,) * (psi.ndim - 1)) * p).astype(np.complex128)
+    for j in (range(n) if targets is None else targets):
+        flipped = np.flip(p, axis=j)
+        sl_r = [slice(None)] * p.ndim
+        sl_g = [slice(None)] * p.ndim
+        sl_r[j] = slice(0, 1)
+        sl_g[j] = slice(1, 2)
+        out[tuple(sl_g)] += c * flipped[tuple(sl_g)]
+        out[tuple(sl_r)] += np.conj(c) * flipped[tuple(sl_r)]
+    return out.reshape(psi.shape)
+
+
+def krylov_map_matrix_free(terms: HamTerms, psi0: np.ndarray, tsave: np.ndarray,
+                           save_all: bool = True, tol: float = 1e-13) -> np.ndarray:
+    """Same map as krylov_map_dense, matrix-free (numpy) for registers too large for dense H."""
+    n = terms.n_qubits
+    occ = occupation_table(n).numpy()
+    udiag = interaction_diagonal(n, terms.u_pairs.detach()).numpy()
+    amp = terms.amp_coeff.detach().numpy() if terms.amp_coeff is not None else None
+    det = terms.det_coeff.detach().numpy() if terms.det_coeff is not None else None
+    psi = np.array(psi0, dtype=np.complex128)
+    out = [psi.copy()]
+    for k in range(len(tsave) - 1):
+        t = float(tsave[k + 1])
+        i1, i2 = interp_indices(t, terms.dt, terms.n_samples)
+        frac = (t - i1 * terms.dt) / terms.dt
+        diag = udiag.copy()
+        if det is not None:
+            d = det[i1] + (det[i2] - det[i1]) * frac
+            for j in terms.det_targets:
+                diag = diag + 2.0 * d * occ[j]
+        c = 0.0j
+        if amp is not None:
+            c = amp[i1] + (amp[i2] - amp[i1]) * frac
+        tau = float(tsave[k + 1] - tsave[k])
+        cols = []
+        for b in range(psi.shape[1]):
+            cols.append(lanczos_expm_multiply(
+                lambda v: structured_matvec_numpy(n, diag, c, v, terms.amp_targets), psi[:, b], tau, tol=tol))
+        psi = np.stack(cols, axis=1)
+        if save_all:
+            out.append(psi.copy())
+    if not save_all:
+        out.append(psi.copy())
+    return np.stack(out)
+
+
+# Dormand-Prince 5(4) tableau (pyqtorch DP5_SE restated: adaptive, RHS -i H(t) psi)
+_DP_C = [0.0, 1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0]
+_DP_A = [
+    [],
+    [1 / 5],
+    [3 / 40, 9 / 40],
+    [44 / 45, -56 / 15, 32 / 9],
+    [19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729],
+    [9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656],
+    [35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84],
+]
+_DP_B5 = [35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84, 0.0]
+_DP_B4 = [5179 / 57600, 0.0, 7571 / 16695, 393 / 640, -92097 / 339200, 187 / 2100, 1 / 40]
+
+
+def dp5_solve(rhs: Callable[[float, np.ndarray], np.ndarray], y0: np.ndarray, tsave: np.ndarray,
+              atol: float = 1e-8, rtol: float = 1e-6, h0: float | None = None) -> np.ndarray:
+    """Adaptive Dormand-Prince 5(4), error-controlled sub-steps between tsave points.
+    Defaults atol 1e-8 / rtol 1e-6 are pyqtorch's as recalled (unverified; KA-1 agrees to 7e-5)."""
+    y = np.array(y0, dtype=np.complex128)
+    out = [y.copy()]
+    h = h0 if h0 is not None else max(float(tsave[1] - tsave[0]) * 0.1, 1e-6)
+    t = float(tsave[0])
+    for k in range(1, len(tsave)):
+        t_end = float(tsave[k])
+        while t < t_end - 1e-15:
+            h_try = min(h, t_end - t)
+            ks = []
+            for s in range(7):
+                ys = y.copy()
+                for a, kk in zip(_DP_A[s], ks):
+                    if a != 0.0:
+                        ys = ys + h_try * a * kk
+                ks.append(rhs(t + _DP_C[s] * h_try, ys))
+            y5 = y + h_try * sum(b * kk for b, kk in zip(_DP_B5, ks) if b != 0.0)
+            y4 = y + h_try * sum(b * kk for b, kk in zip(_DP_B4, ks) if b != 0.0)
+            scale = atol + rtol * np.maximum(np.abs(y), np.abs(y5))
+            err = np.sqrt(np.mean((np.abs(y5 - y4) / scale) ** 2))
+            if err <= 1.0:
+                t += h_try
+                y = y5
+            fac = 0.9 * (1.0 / max(err, 1e-16)) ** 0.2
+            h = h_try * min(5.0, max(0.2, fac))
+        t = t_end
+        out.append(y.copy())
+    return np.stack(out)
+
+
+def make_rhs(terms: HamTerms) -> Callable[[float, np.ndarray], np.ndarray]:
+    """RHS -i H(t) psi with H(t) from the interpolation rule of hamiltonian.py:526-546 (matrix-free)."""
+    n = terms.n_qubits
+    occ = occupation_table(n).numpy()
+    udiag = interaction_diagonal(n, terms.u_pairs.detach()).numpy()
+    amp = terms.amp_coeff.detach().numpy() if terms.amp_coeff is not None else None
+    det = terms.det_coeff.detach().numpy() if terms.det_coeff is not None else None
+    occ_det = sum(occ[j] for j in terms.det_targets) if terms.det_targets else 0.0
+
+    def rhs(t: float, psi: np.ndarray) -> np.ndarray:
+        i1, i2 = interp_indices(t, terms.dt, terms.n_samples)
+        frac = (t - i1 * terms.dt) / terms.dt
+        diag = udiag
+        if det is not None:
+            diag = udiag + 2.0 * (det[i1] + (det[i2] - det[i1]) * frac) * occ_det
+        c = (amp[i1] + (amp[i2] - amp[i1]) * frac) if amp is not None else 0.0j
+        return -1j * structured_matvec_numpy(n, diag, c, psi, terms.amp_targets)
+
+    return rhs
+
+
+def continuous_solution(terms: HamTerms, psi0: np.ndarray, tsave: np.ndarray,
+                        rtol: float = 1e-12, atol: float = 1e-14) -> np.ndarray:
+    """DP5_SE's *target*: the continuous-time solution, integrated to tight tolerance (scipy DOP853)."""
+    from scipy.integrate import solve_ivp
+
+    rhs = make_rhs(terms)
+    shape = np.asarray(psi0).shape
+    sol = solve_ivp(lambda t, y: rhs(t, y.reshape(shape)).reshape(-1), (float(tsave[0]), float(tsave[-1])),
+                    np.asarray(psi0, dtype=np.complex128).reshape(-1), method="DOP853", t_eval=np.asarray(tsave),
+                    rtol=rtol, atol=atol, max_step=float(terms.dt))
+    return sol.y.T.reshape((len(tsave),) + shape)
