@@ -1,0 +1,156 @@
+/*
+ * rydiff.h — C ABI of the MI355X-native differentiable Rydberg time-evolution library.
+ *
+ * This is the drop-in boundary for ONE hot path of pasqal-io/pulser-diff: the solver seam
+ *
+ *     pulser_diff/backend.py:488-494      result = sesolve(H=H_t, psi0, tsave, solver, options)
+ *
+ * together with the Hamiltonian closure it calls on every sub-step
+ *
+ *     pulser_diff/hamiltonian.py:499-548  build_ham_tensor(qobj_list) -> H_t(t)
+ *
+ * and the observable / autograd legs that hang off it
+ *
+ *     pulser_diff/utils.py:68-86          expect(obs, states)        (ket branch :79-81)
+ *     pulser_diff/derivative.py:40,76     torch.autograd.grad(f, x, v, retain_graph=True)
+ *
+ * The reference hands the solver an opaque Python callable H_t that re-assembles a sparse
+ * 2^N x 2^N matrix per call.  This library replaces seam + closure by a STRUCTURED problem:
+ * the coefficient arrays the reference captures in `build_ham_tensor` (amp_values /
+ * det_values, hamiltonian.py:507-520), the qubits each operator acts on, the pair
+ * interaction strengths (hamiltonian.py:343, :536), dt and n_samples (hamiltonian.py:523-524),
+ * tsave and psi0 (backend.py:490-491).  H is never materialised.
+ *
+ * Conventions (fixed by the reference):
+ *   - basis r=0, g=1 per qubit; qubit 0 is the MOST significant bit of the amplitude index
+ *     (hamiltonian.py:299, utils.py:127-129);  n_j(x) = 1 - bit_j(x).
+ *   - (H psi)[x] = [sum_{i<j} U_ij n_i n_j + sum_terms 2*det_k(t) * sum_{j in mask_k} n_j] psi[x]
+ *                  + sum_terms sum_{j in mask_k} ( amp_k(t) if bit_j(x)=1 else conj(amp_k(t)) ) psi[x ^ m_j]
+ *     where amp_k = 0.5*Omega*exp(-i*phi) and det_k = -0.5*delta are the reference's own
+ *     coefficient arrays (hamiltonian.py:420-423, 439-442) and the factor 2 is its
+ *     `ham_mat + ham_mat.adjoint()` on a diagonal operator (hamiltonian.py:539-540).
+ *   - coefficient at time t: linear interpolation between samples i1 = max(min(floor(t/dt), n-2), 0)
+ *     and i2 = min(i1+1, n-2) (hamiltonian.py:532-542).
+ *   - states are complex128, laid out (n_tsave, batch, 2^N) with the amplitude index fastest;
+ *     the reference's (n_t, dim, B) (simresults.py:398-401) is the permuted view.
+ *
+ * Ownership: every pointer marked DEVICE is device memory owned by the caller (torch);
+ * pointers marked HOST are host memory.  The library allocates nothing on the device: the
+ * caller passes a workspace sized by rydiff_plan().  All work is enqueued on `stream`.
+ * Functions return 0 on success, a negative RYDIFF_E* code otherwise; rydiff_last_error()
+ * gives the message (thread-local).  The library never aborts.
+ */
+#ifndef RYDIFF_H
+#define RYDIFF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RYDIFF_MAX_QUBITS 30
+#define RYDIFF_MAX_TERMS 64
+
+enum { RYDIFF_OK = 0, RYDIFF_EINVAL = -1, RYDIFF_EWORKSPACE = -2, RYDIFF_EHIP = -3, RYDIFF_ENOTIMPL = -4 };
+
+/* SolverType member names mirror pyqtorch.utils.SolverType as used at backend.py:434,487. */
+enum { RYDIFF_SOLVER_KRYLOV_SE = 0, RYDIFF_SOLVER_DP5_SE = 1 };
+
+typedef struct RydProblem {
+    int32_t n_qubits;      /* N, 1..RYDIFF_MAX_QUBITS */
+    int32_t batch;         /* B: number of state columns / trajectories (backend.py:266-280: psi0 is (dim, B)) */
+    int32_t coeff_batch;   /* 1: all trajectories share the coefficient tables; B: one table set per trajectory */
+    int32_t n_samples;     /* n: length of every coefficient array (hamiltonian.py:524) */
+    double dt;             /* 0.001 / sampling_rate, in us (hamiltonian.py:523) */
+
+    int32_t n_amp_terms;   /* off-diagonal terms ("amp_matrices", hamiltonian.py:517-520) */
+    int32_t n_det_terms;   /* diagonal terms ("det_matrices", hamiltonian.py:513-516) */
+    const uint32_t* amp_masks;  /* HOST [n_amp_terms]; bit j set = term acts on qubit j (global = all qubits, backend.py:102-112) */
+    const uint32_t* det_masks;  /* HOST [n_det_terms] */
+    const void* amp_tables;     /* DEVICE complex128 [coeff_batch][n_amp_terms][n_samples] = 0.5*amp*exp(-i*phase) */
+    const double* det_tables;   /* DEVICE float64    [coeff_batch][n_det_terms][n_samples] = -0.5*det */
+    const double* u_pairs;      /* DEVICE float64 [N(N-1)/2], U_ij = C6/r_ij^6 in itertools.combinations order (hamiltonian.py:385) */
+
+    int32_t n_tsave;       /* number of evaluation times (backend.py:364-373), >= 2 */
+    const double* tsave;   /* HOST float64 [n_tsave], strictly increasing, in us */
+
+    int32_t solver;        /* RYDIFF_SOLVER_* */
+    double tol;            /* per-exponential truncation target (<=0: default 1e-13) */
+
+    int32_t n_obs;         /* diagonal observables evaluated at every tsave (utils.py:79-81 for diagonal O) */
+    const double* obs_diag;/* DEVICE float64 [n_obs][2^N] */
+} RydProblem;
+
+/* Result of rydiff_plan(): everything that depends on the VALUES in the coefficient tables. */
+typedef struct RydPlanInfo {
+    double spectral_lo, spectral_hi; /* rigorous bounds on the spectrum of H(t) over the whole run (Gershgorin) */
+    double rho_design;               /* max over exponentials of tau * (hi-lo)/2 after sub-stepping */
+    int32_t degree;                  /* polynomial degree = matrix-free H applications per (sub-)exponential */
+    int32_t n_stages;                /* exponentials in the run (KRYLOV_SE: one per tsave interval) */
+    int32_t max_step_factors;        /* largest number of factor passes inside one tsave interval */
+    int32_t reserved;
+    int64_t total_factors;           /* factor passes of one forward run = H applications per trajectory */
+    size_t workspace_bytes;          /* device workspace needed by forward/backward for the flags given to rydiff_plan */
+} RydPlanInfo;
+
+#define RYDIFF_PLAN_SCRATCH_BYTES 1024
+
+/* Inspect the coefficient tables (one tiny kernel + ONE stream synchronisation), bound the spectrum,
+ * choose sub-steps and polynomial degree, and size the workspace.
+ *   need_tape      != 0: reserve room for the (n_tsave, B, 2^N) trajectory inside the workspace (caller passes
+ *                        states_out == NULL but wants gradients)
+ *   need_backward  != 0: reserve the backward-sweep buffers too
+ *   scratch        DEVICE, >= RYDIFF_PLAN_SCRATCH_BYTES */
+int rydiff_plan(const RydProblem* p, int need_tape, int need_backward, void* scratch, void* stream, RydPlanInfo* info);
+
+/* Forward: replaces sesolve(H_t, psi0, tsave, solver, options).states (backend.py:488-494,513-521)
+ * and SimulationResults.expect for diagonal observables (simresults.py:81-129).
+ *   info        HOST: result of rydiff_plan for the SAME table values (no synchronisation then), or NULL to plan
+ *               internally (one synchronisation; workspace must then be large enough, see RYDIFF_EWORKSPACE)
+ *   psi0        DEVICE complex128 [B][2^N]
+ *   states_out  DEVICE complex128 [n_tsave][B][2^N], or NULL (trajectory kept in the workspace tape if need_tape)
+ *   expect_out  DEVICE float64 [n_obs][n_tsave][B], or NULL */
+int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi0, void* states_out, double* expect_out,
+                   void* workspace, size_t workspace_bytes, int need_tape, void* stream);
+
+/* Backward (vector-Jacobian product): replaces torch autograd's tape through every solver
+ * sub-step (derivative.py:40,76).  Cotangents use torch's convention for complex tensors
+ * (grad = dL/dRe + i dL/dIm).  The workspace must be the one the forward call used when the
+ * trajectory lives in its tape (states == NULL).
+ *   states       DEVICE: the states_out of the forward call, or NULL to use the workspace tape
+ *   grad_states  DEVICE complex128 [n_tsave][B][2^N] or NULL
+ *   grad_expect  DEVICE float64 [n_obs][n_tsave][B] or NULL
+ *   g_amp        DEVICE complex128 [coeff_batch][n_amp_terms][n_samples] or NULL   (overwritten)
+ *   g_det        DEVICE float64    [coeff_batch][n_det_terms][n_samples] or NULL   (overwritten)
+ *   g_u          DEVICE float64 [N(N-1)/2] or NULL  (dist_grad, backend.py:456-460 / hamiltonian.py:341-344)
+ *   g_tsave      DEVICE float64 [n_tsave] or NULL   (time_grad, backend.py:453-455)
+ *   g_psi0       DEVICE complex128 [B][2^N] or NULL */
+int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* states, const void* grad_states,
+                    const double* grad_expect, void* g_amp, double* g_det, double* g_u, double* g_tsave, void* g_psi0,
+                    void* workspace, size_t workspace_bytes, int need_tape, void* stream);
+
+/* One matrix-free application y = H(coefficients) x on DEVICE buffers, for get_hamiltonian-style
+ * checks (backend.py:401-427) and micro-benchmarks.  c_amp: HOST complex (re,im) per amp term,
+ * c_det: HOST value per det term (already interpolated, reference units as above). */
+int rydiff_apply_hamiltonian(const RydProblem* p, const double* c_amp_reim, const double* c_det,
+                             const void* x, void* y, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Host-only helper (no GPU needed): design the product-form polynomial used for exp(-i*rho*x), x in [-1,1].
+ * Writes the degree to *degree and roots (re,im interleaved) to roots_reim[2*max_degree]; returns the
+ * measured max |p(x) - exp(-i rho x)| on a test grid in *max_err.  Exposed so the host logic is testable on CPU. */
+int rydiff_design_polynomial(double rho, double tol, int max_degree, int* degree, double* roots_reim,
+                             double* p0_reim, double* max_err);
+
+/* Selects the kernel implementation: 0 = auto, 1 = direct (one amplitude per thread, global partner loads),
+ * 2 = LDS-tiled chained passes.  Used by parity tests to A/B the kernels against each other. */
+int rydiff_set_kernel_variant(int variant);
+
+const char* rydiff_last_error(void);
+const char* rydiff_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RYDIFF_H */

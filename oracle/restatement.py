@@ -152,8 +152,10 @@ def pair_distances(coords: Tensor) -> list[Tensor]:
 
 def interaction_strengths(coords: Tensor, c6: float = C6_MOCK_DEVICE) -> Tensor:
     """U_ij = C6 / r_ij^6 (net of hamiltonian.py:343 `0.5*C6/dist**6` and :536 `2*int_mat`)."""
-    d = torch.stack(pair_distances(torch.as_tensor(coords, dtype=RDTYPE)))
-    return c6 / d**6
+    dists = pair_distances(torch.as_tensor(coords, dtype=RDTYPE))
+    if not dists:  # single qubit: no interaction term (hamiltonian.py:501-505)
+        return torch.zeros(0, dtype=RDTYPE)
+    return c6 / torch.stack(dists) ** 6
 
 
 @dataclass
@@ -172,6 +174,16 @@ class HamTerms:
     n_samples: int  # hamiltonian.py:524
     amp_targets: list[int] = field(default_factory=list)  # qubits driven (global => all)
     det_targets: list[int] = field(default_factory=list)
+    # further terms, e.g. Local-channel ones (hamiltonian.py:435-452): (coefficient array, target qubits)
+    extra_amp: list = field(default_factory=list)
+    extra_det: list = field(default_factory=list)
+
+    def amp_terms(self) -> list:
+        """All off-diagonal terms in the reference's order (Global first, then Local; hamiltonian.py:487-490)."""
+        return ([(self.amp_coeff, self.amp_targets)] if self.amp_coeff is not None else []) + list(self.extra_amp)
+
+    def det_terms(self) -> list:
+        return ([(self.det_coeff, self.det_targets)] if self.det_coeff is not None else []) + list(self.extra_det)
 
 
 def build_terms(seq: SampledGlobalSequence, coords: Tensor, sampling_rate: float,
@@ -237,14 +249,14 @@ def dense_hamiltonian(terms: HamTerms, t) -> Tensor:
     occ = occupation_table(n)
     diag = interaction_diagonal(n, terms.u_pairs).to(CDTYPE)
     ham = torch.diag(diag)
-    if terms.det_coeff is not None:
-        d = interp_coeff(terms.det_coeff, t, terms.dt, terms.n_samples)  # = -0.5*det(t)
-        for j in terms.det_targets:
+    for coeff, targets in terms.det_terms():
+        d = interp_coeff(coeff, t, terms.dt, terms.n_samples)  # = -0.5*det(t)
+        for j in targets:
             ham = ham + torch.diag((2.0 * d * occ[j]).to(CDTYPE))
-    if terms.amp_coeff is not None:
-        c = interp_coeff(terms.amp_coeff, t, terms.dt, terms.n_samples)
-        x = np.arange(dim)
-        for j in terms.amp_targets:
+    x = np.arange(dim)
+    for coeff, targets in terms.amp_terms():
+        c = interp_coeff(coeff, t, terms.dt, terms.n_samples)
+        for j in targets:
             m = 1 << (n - 1 - j)
             rows_g = torch.as_tensor(x[(x & m) != 0])
             lower = torch.zeros(dim, dim, dtype=CDTYPE)
@@ -288,31 +300,29 @@ def reference_style_operators(terms: HamTerms):
     int_mat = torch.sparse_coo_tensor(torch.zeros(2, 1, dtype=torch.long), torch.zeros(1, dtype=CDTYPE), (dim, dim))
     for k, (i, j) in enumerate(itertools.combinations(range(n), 2)):
         int_mat = int_mat + build("sigma_rr", [i, j]) * (0.5 * terms.u_pairs[k]).to(CDTYPE)
-    amp_mat = det_mat = None
-    if terms.amp_coeff is not None:
-        amp_mat = sum((build("sigma_gr", [q]) for q in terms.amp_targets[1:]), build("sigma_gr", [terms.amp_targets[0]]))
-    if terms.det_coeff is not None:
-        det_mat = sum((build("sigma_rr", [q]) for q in terms.det_targets[1:]), build("sigma_rr", [terms.det_targets[0]]))
-    return int_mat.coalesce(), amp_mat, det_mat
+    def summed(opname: str, targets: list[int]) -> Tensor:
+        return sum((build(opname, [q]) for q in targets[1:]), build(opname, [targets[0]]))
+
+    amp_mats = [(summed("sigma_gr", tg), c) for c, tg in terms.amp_terms()]
+    det_mats = [(summed("sigma_rr", tg), (1.0 + 0.0j) * c) for c, tg in terms.det_terms()]
+    return int_mat.coalesce(), amp_mats, det_mats
 
 
 def reference_style_H_t(terms: HamTerms) -> Callable[[float], Tensor]:
     """hamiltonian.py:499-548: returns the closure that RE-ASSEMBLES sparse H on every call."""
-    int_mat, amp_mat, det_mat = reference_style_operators(terms)
+    int_mat, amp_mats, det_mats = reference_style_operators(terms)
     dt, n_samples = terms.dt, terms.n_samples
-    det_val = (1.0 + 0.0j) * terms.det_coeff if terms.det_coeff is not None else None
-    amp_val = terms.amp_coeff
 
     def H_t(t):
         if not isinstance(t, Tensor):
             t = torch.tensor(t, dtype=RDTYPE)
         i1, i2 = interp_indices(float(t), dt, n_samples)
         ham = 2 * int_mat
-        if det_mat is not None:
+        for det_mat, det_val in det_mats:
             det = det_val[i1] + (det_val[i2] - det_val[i1]) * (t - i1 * dt) / dt
             ham_mat = det_mat * det
             ham = ham + ham_mat + ham_mat.adjoint()
-        if amp_mat is not None:
+        for amp_mat, amp_val in amp_mats:
             amp = amp_val[i1] + (amp_val[i2] - amp_val[i1]) * (t - i1 * dt) / dt
             ham_mat = amp_mat * amp
             ham = ham + ham_mat + ham_mat.adjoint()
@@ -410,33 +420,46 @@ def structured_matvec_numpy(n: int, diag: np.ndarray, c: complex, psi: np.ndarra
     return out.reshape(psi.shape)
 
 
-def krylov_map_matrix_free(terms: HamTerms, psi0: np.ndarray, tsave: np.ndarray,
-                           save_all: bool = True, tol: float = 1e-13) -> np.ndarray:
-    """Same map as krylov_map_dense, matrix-free (numpy) for registers too large for dense H."""
+def _matrix_free_tables(terms: HamTerms):
     n = terms.n_qubits
     occ = occupation_table(n).numpy()
     udiag = interaction_diagonal(n, terms.u_pairs.detach()).numpy()
-    amp = terms.amp_coeff.detach().numpy() if terms.amp_coeff is not None else None
-    det = terms.det_coeff.detach().numpy() if terms.det_coeff is not None else None
+    amps = [(c.detach().numpy(), list(tg)) for c, tg in terms.amp_terms()]
+    dets = [(c.detach().numpy(), sum(occ[j] for j in tg)) for c, tg in terms.det_terms()]
+    return n, udiag, amps, dets
+
+
+def _matrix_free_apply(n, udiag, amps, dets, i1, i2, frac, psi):
+    diag = udiag
+    for d, occ_sum in dets:
+        diag = diag + 2.0 * (d[i1] + (d[i2] - d[i1]) * frac) * occ_sum
+    out = None
+    first = True
+    for a, targets in amps:
+        c = a[i1] + (a[i2] - a[i1]) * frac
+        part = structured_matvec_numpy(n, diag if first else np.zeros_like(udiag), c, psi, targets)
+        out = part if out is None else out + part
+        first = False
+    if out is None:
+        out = diag.reshape((-1,) + (1,) * (psi.ndim - 1)) * psi
+    return out
+
+
+def krylov_map_matrix_free(terms: HamTerms, psi0: np.ndarray, tsave: np.ndarray,
+                           save_all: bool = True, tol: float = 1e-13) -> np.ndarray:
+    """Same map as krylov_map_dense, matrix-free (numpy) for registers too large for dense H."""
+    n, udiag, amps, dets = _matrix_free_tables(terms)
     psi = np.array(psi0, dtype=np.complex128)
     out = [psi.copy()]
     for k in range(len(tsave) - 1):
         t = float(tsave[k + 1])
         i1, i2 = interp_indices(t, terms.dt, terms.n_samples)
         frac = (t - i1 * terms.dt) / terms.dt
-        diag = udiag.copy()
-        if det is not None:
-            d = det[i1] + (det[i2] - det[i1]) * frac
-            for j in terms.det_targets:
-                diag = diag + 2.0 * d * occ[j]
-        c = 0.0j
-        if amp is not None:
-            c = amp[i1] + (amp[i2] - amp[i1]) * frac
         tau = float(tsave[k + 1] - tsave[k])
         cols = []
         for b in range(psi.shape[1]):
             cols.append(lanczos_expm_multiply(
-                lambda v: structured_matvec_numpy(n, diag, c, v, terms.amp_targets), psi[:, b], tau, tol=tol))
+                lambda v: _matrix_free_apply(n, udiag, amps, dets, i1, i2, frac, v), psi[:, b], tau, tol=tol))
         psi = np.stack(cols, axis=1)
         if save_all:
             out.append(psi.copy())
@@ -495,21 +518,12 @@ def dp5_solve(rhs: Callable[[float, np.ndarray], np.ndarray], y0: np.ndarray, ts
 
 def make_rhs(terms: HamTerms) -> Callable[[float, np.ndarray], np.ndarray]:
     """RHS -i H(t) psi with H(t) from the interpolation rule of hamiltonian.py:526-546 (matrix-free)."""
-    n = terms.n_qubits
-    occ = occupation_table(n).numpy()
-    udiag = interaction_diagonal(n, terms.u_pairs.detach()).numpy()
-    amp = terms.amp_coeff.detach().numpy() if terms.amp_coeff is not None else None
-    det = terms.det_coeff.detach().numpy() if terms.det_coeff is not None else None
-    occ_det = sum(occ[j] for j in terms.det_targets) if terms.det_targets else 0.0
+    n, udiag, amps, dets = _matrix_free_tables(terms)
 
     def rhs(t: float, psi: np.ndarray) -> np.ndarray:
         i1, i2 = interp_indices(t, terms.dt, terms.n_samples)
         frac = (t - i1 * terms.dt) / terms.dt
-        diag = udiag
-        if det is not None:
-            diag = udiag + 2.0 * (det[i1] + (det[i2] - det[i1]) * frac) * occ_det
-        c = (amp[i1] + (amp[i2] - amp[i1]) * frac) if amp is not None else 0.0j
-        return -1j * structured_matvec_numpy(n, diag, c, psi, terms.amp_targets)
+        return -1j * _matrix_free_apply(n, udiag, amps, dets, i1, i2, frac, psi)
 
     return rhs
 

@@ -1,0 +1,152 @@
+"""ctypes binding of the C ABI in ``include/rydiff.h`` (``csrc/librydiff.so``, built for gfx950).
+
+No torch types cross this boundary: only raw device pointers (``tensor.data_ptr()``), sizes and the
+HIP stream handle.  The product path FAILS LOUDLY when the library is missing — there is no CPU or
+eager-PyTorch fallback (the CPU oracle under ``oracle/`` is test infrastructure and is never imported
+from here).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from pathlib import Path
+
+_CSRC = Path(__file__).resolve().parent / "csrc"
+_LIB_PATH = _CSRC / "librydiff.so"
+
+RYDIFF_OK = 0
+RYDIFF_EINVAL = -1
+RYDIFF_EWORKSPACE = -2
+RYDIFF_EHIP = -3
+RYDIFF_ENOTIMPL = -4
+SOLVER_KRYLOV_SE = 0
+SOLVER_DP5_SE = 1
+PLAN_SCRATCH_BYTES = 1024
+MAX_QUBITS = 30
+MAX_TERMS = 64
+
+
+class RydProblem(ctypes.Structure):
+    _fields_ = [
+        ("n_qubits", ctypes.c_int32),
+        ("batch", ctypes.c_int32),
+        ("coeff_batch", ctypes.c_int32),
+        ("n_samples", ctypes.c_int32),
+        ("dt", ctypes.c_double),
+        ("n_amp_terms", ctypes.c_int32),
+        ("n_det_terms", ctypes.c_int32),
+        ("amp_masks", ctypes.c_void_p),
+        ("det_masks", ctypes.c_void_p),
+        ("amp_tables", ctypes.c_void_p),
+        ("det_tables", ctypes.c_void_p),
+        ("u_pairs", ctypes.c_void_p),
+        ("n_tsave", ctypes.c_int32),
+        ("tsave", ctypes.c_void_p),
+        ("solver", ctypes.c_int32),
+        ("tol", ctypes.c_double),
+        ("n_obs", ctypes.c_int32),
+        ("obs_diag", ctypes.c_void_p),
+    ]
+
+
+class RydPlanInfo(ctypes.Structure):
+    _fields_ = [
+        ("spectral_lo", ctypes.c_double),
+        ("spectral_hi", ctypes.c_double),
+        ("rho_design", ctypes.c_double),
+        ("degree", ctypes.c_int32),
+        ("n_stages", ctypes.c_int32),
+        ("max_step_factors", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+        ("total_factors", ctypes.c_int64),
+        ("workspace_bytes", ctypes.c_size_t),
+    ]
+
+
+EXPORTS = (
+    "rydiff_plan",
+    "rydiff_forward",
+    "rydiff_backward",
+    "rydiff_apply_hamiltonian",
+    "rydiff_design_polynomial",
+    "rydiff_set_kernel_variant",
+    "rydiff_last_error",
+    "rydiff_version",
+)
+
+_lib = None
+
+
+def build(force: bool = False) -> Path:
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force or not _LIB_PATH.exists():
+        subprocess.run(["make", "-C", str(_CSRC)] + (["-B"] if force else []), check=True)
+    return _LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise RuntimeError(
+            f"{_LIB_PATH} is missing: the HIP extension has not been built. Run `python -c 'import "
+            "__graft_entry__ as g; g.build()'` (or `make -C pulser-diff_amd/csrc`). There is no CPU fallback."
+        )
+    L = ctypes.CDLL(str(_LIB_PATH))
+    vp, i32, dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+    L.rydiff_plan.argtypes = [ctypes.POINTER(RydProblem), i32, i32, vp, vp, ctypes.POINTER(RydPlanInfo)]
+    L.rydiff_plan.restype = i32
+    L.rydiff_forward.argtypes = [ctypes.POINTER(RydProblem), ctypes.POINTER(RydPlanInfo), vp, vp, vp, vp,
+                                 ctypes.c_size_t, i32, vp]
+    L.rydiff_forward.restype = i32
+    L.rydiff_backward.argtypes = [ctypes.POINTER(RydProblem), ctypes.POINTER(RydPlanInfo), vp, vp, vp, vp, vp, vp,
+                                  vp, vp, vp, ctypes.c_size_t, i32, vp]
+    L.rydiff_backward.restype = i32
+    L.rydiff_apply_hamiltonian.argtypes = [ctypes.POINTER(RydProblem), vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    L.rydiff_apply_hamiltonian.restype = i32
+    L.rydiff_design_polynomial.argtypes = [dbl, dbl, i32, ctypes.POINTER(i32), vp, vp, ctypes.POINTER(dbl)]
+    L.rydiff_design_polynomial.restype = i32
+    L.rydiff_set_kernel_variant.argtypes = [i32]
+    L.rydiff_set_kernel_variant.restype = i32
+    L.rydiff_last_error.restype = ctypes.c_char_p
+    L.rydiff_version.restype = ctypes.c_char_p
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return lib().rydiff_last_error().decode()
+
+
+def check(rc: int) -> None:
+    """Map C error codes onto the exception types the reference raises."""
+    if rc == RYDIFF_OK:
+        return
+    msg = last_error()
+    if rc == RYDIFF_EINVAL:
+        raise ValueError(msg)
+    if rc == RYDIFF_ENOTIMPL:
+        raise NotImplementedError(msg)
+    if rc == RYDIFF_EWORKSPACE:
+        raise MemoryError(msg)
+    raise RuntimeError(f"rydiff (HIP) error {rc}: {msg}")
+
+
+def design_polynomial(rho: float, tol: float = 1e-13, max_degree: int = 120):
+    """Host-only helper (works without a GPU): roots of the product-form polynomial for exp(-i rho x)."""
+    import numpy as np
+
+    deg = ctypes.c_int()
+    roots = np.zeros(2 * max_degree)
+    p0 = np.zeros(2)
+    err = ctypes.c_double()
+    check(lib().rydiff_design_polynomial(rho, tol, max_degree, ctypes.byref(deg), roots.ctypes.data, p0.ctypes.data,
+                                         ctypes.byref(err)))
+    m = deg.value
+    return roots[: 2 * m].view(np.complex128).copy(), complex(p0[0], p0[1]), err.value
+
+
+def set_kernel_variant(variant: int) -> None:
+    check(lib().rydiff_set_kernel_variant(int(variant)))

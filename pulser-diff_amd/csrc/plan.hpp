@@ -1,0 +1,238 @@
+// Host-side planning: validates a RydProblem, groups qubits that share coefficients, builds the list
+// of exponential "stages" (one per tsave interval for KRYLOV_SE) and carves the device workspace.
+//
+// Reference semantics restated here:
+//   interpolation indices / weights      pulser_diff/hamiltonian.py:532-542
+//   KRYLOV_SE right-endpoint H freezing  SURVEY.md section 8 a-4 (pinned by notebook outputs KA-2..4)
+//   term -> qubit maps                   pulser_diff/hamiltonian.py:419-452, backend.py:102-112
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rydiff.h"
+
+namespace rydiff {
+
+constexpr int kMaxGroups = RYDIFF_MAX_QUBITS;  // at most one coefficient group per qubit
+constexpr double kRhoCap = 6.0;                // per-exponential spectral radius*tau cap (sub-steps above it)
+constexpr size_t kAlign = 256;
+
+struct Stage {
+    double tau;        // duration of this exponential
+    int step;          // tsave interval it belongs to
+    int nsub;          // sub-steps (set once the spectral width is known)
+    int idx[4];        // sample indices entering the coefficient combination
+    double w[4];       // their weights
+    double dwdt[4];    // d w / d tsave[tnode]
+    int tnode;         // tsave index the interpolation time is tied to
+    int t_hi, t_lo;    // tau = tau_scale * (tsave[t_hi] - tsave[t_lo])
+    double tau_scale;
+};
+
+struct Groups {
+    int n = 0;
+    uint32_t amp_index_mask[kMaxGroups];  // bits of the AMPLITUDE index (qubit j <-> bit N-1-j)
+    uint64_t members[kMaxGroups];         // which terms contribute to this group's coefficient
+    int count[kMaxGroups];                // qubits in the group
+};
+
+struct Plan {
+    int N = 0;
+    size_t dim = 0;
+    int B = 1, Bc = 1, T = 0, n_samples = 0, Ka = 0, Kd = 0, n_obs = 0, solver = 0;
+    double dt = 0.0, tol = 1e-13;
+    Groups ga, gd;
+    int NC = 0;  // doubles per (trajectory, stage) coefficient record: c_re[Ga], c_im[Ga], dcoef[Gd]
+    std::vector<Stage> stages;
+    std::vector<int> step_begin;  // stages of step k are [step_begin[k], step_begin[k+1])
+    std::vector<double> tsave;
+
+    // workspace offsets (bytes)
+    size_t off_meta_idx = 0, off_meta_w = 0, off_coef = 0, off_stats = 0, off_udiag = 0, off_buf0 = 0, off_buf1 = 0;
+    size_t off_tape = 0, off_chain = 0, off_ge = 0, off_wtot = 0, off_members = 0, off_meta2 = 0;
+    size_t state_bytes = 0;  // B * dim * 16
+    size_t total_fwd = 0;
+    int chain_slots = 0;
+};
+
+inline size_t align_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
+
+inline bool build_groups(int N, int n_terms, const uint32_t* masks, Groups& g, std::string& err) {
+    g.n = 0;
+    if (n_terms > RYDIFF_MAX_TERMS) {
+        err = "too many terms (max " + std::to_string(RYDIFF_MAX_TERMS) + ")";
+        return false;
+    }
+    for (int j = 0; j < N; ++j) {
+        uint64_t sig = 0;
+        for (int k = 0; k < n_terms; ++k)
+            if (masks[k] >> j & 1u) sig |= (1ull << k);
+        if (!sig) continue;
+        int found = -1;
+        for (int q = 0; q < g.n; ++q)
+            if (g.members[q] == sig) found = q;
+        if (found < 0) {
+            found = g.n++;
+            g.members[found] = sig;
+            g.amp_index_mask[found] = 0;
+            g.count[found] = 0;
+        }
+        g.amp_index_mask[found] |= (1u << (N - 1 - j));
+        g.count[found] += 1;
+    }
+    for (int k = 0; k < n_terms; ++k) {
+        if (masks[k] == 0 || (N < 32 && (masks[k] >> N) != 0)) {
+            err = "term mask " + std::to_string(k) + " is empty or addresses a qubit >= n_qubits";
+            return false;
+        }
+    }
+    return true;
+}
+
+inline bool build_plan(const RydProblem* p, Plan& pl, std::string& err) {
+    if (!p) {
+        err = "null problem";
+        return false;
+    }
+    if (p->n_qubits < 1 || p->n_qubits > RYDIFF_MAX_QUBITS) {
+        err = "n_qubits out of range";
+        return false;
+    }
+    if (p->batch < 1 || (p->coeff_batch != 1 && p->coeff_batch != p->batch)) {
+        err = "coeff_batch must be 1 or batch";
+        return false;
+    }
+    if (p->n_tsave < 2 || !p->tsave) {
+        err = "need at least two evaluation times";
+        return false;
+    }
+    if (p->n_amp_terms < 0 || p->n_det_terms < 0) {
+        err = "negative term count";
+        return false;
+    }
+    if ((p->n_amp_terms + p->n_det_terms) > 0 && (p->n_samples < 2 || !(p->dt > 0.0))) {
+        err = "coefficient tables need n_samples >= 2 and dt > 0";
+        return false;
+    }
+    if ((p->n_amp_terms > 0 && (!p->amp_tables || !p->amp_masks)) || (p->n_det_terms > 0 && (!p->det_tables || !p->det_masks))) {
+        err = "missing coefficient tables or masks";
+        return false;
+    }
+    if (p->n_qubits > 1 && !p->u_pairs) {
+        err = "u_pairs is required for more than one qubit";
+        return false;
+    }
+    if (p->n_obs < 0 || (p->n_obs > 0 && !p->obs_diag)) {
+        err = "obs_diag missing";
+        return false;
+    }
+    if (p->solver != RYDIFF_SOLVER_KRYLOV_SE && p->solver != RYDIFF_SOLVER_DP5_SE) {
+        err = "unknown solver";
+        return false;
+    }
+    pl.N = p->n_qubits;
+    pl.dim = size_t(1) << pl.N;
+    pl.B = p->batch;
+    pl.Bc = p->coeff_batch;
+    pl.T = p->n_tsave - 1;
+    pl.n_samples = p->n_samples;
+    pl.Ka = p->n_amp_terms;
+    pl.Kd = p->n_det_terms;
+    pl.n_obs = p->n_obs;
+    pl.dt = p->dt;
+    pl.solver = p->solver;
+    pl.tol = (p->tol > 0.0) ? p->tol : 1e-13;
+    pl.tsave.assign(p->tsave, p->tsave + p->n_tsave);
+    for (int k = 0; k < pl.T; ++k) {
+        if (!(pl.tsave[k + 1] > pl.tsave[k]) || !std::isfinite(pl.tsave[k + 1])) {
+            err = "tsave must be finite and strictly increasing";
+            return false;
+        }
+    }
+    if (!build_groups(pl.N, pl.Ka, p->amp_masks, pl.ga, err)) return false;
+    if (!build_groups(pl.N, pl.Kd, p->det_masks, pl.gd, err)) return false;
+    pl.NC = 2 * pl.ga.n + pl.gd.n;
+
+    pl.stages.clear();
+    pl.step_begin.assign(pl.T + 1, 0);
+    const int n = pl.n_samples;
+    auto node = [&](double t, int tnode, Stage& s, double weight, int slot) {
+        // hamiltonian.py:532-533 / :538,542
+        int i1 = 0, i2 = 0;
+        double frac = 0.0;
+        if (pl.Ka + pl.Kd > 0) {
+            double q = std::floor(t / pl.dt);
+            double lim = double(n - 2);
+            double qq = q < lim ? q : lim;
+            i1 = int(qq) > 0 ? int(qq) : 0;
+            i2 = (i1 + 1 < n - 2) ? i1 + 1 : n - 2;
+            if (i2 < 0) i2 = 0;
+            frac = (t - i1 * pl.dt) / pl.dt;
+        }
+        s.idx[slot] = i1;
+        s.idx[slot + 1] = i2;
+        s.w[slot] = weight * (1.0 - frac);
+        s.w[slot + 1] = weight * frac;
+        s.dwdt[slot] = -weight / pl.dt;
+        s.dwdt[slot + 1] = weight / pl.dt;
+        (void)tnode;
+    };
+    for (int k = 0; k < pl.T; ++k) {
+        pl.step_begin[k] = int(pl.stages.size());
+        if (pl.solver == RYDIFF_SOLVER_KRYLOV_SE) {
+            Stage s{};
+            s.step = k;
+            s.tau = pl.tsave[k + 1] - pl.tsave[k];
+            s.nsub = 1;
+            s.tnode = k + 1;
+            s.t_hi = k + 1;
+            s.t_lo = k;
+            s.tau_scale = 1.0;
+            node(pl.tsave[k + 1], k + 1, s, 1.0, 0);
+            s.idx[2] = s.idx[3] = 0;
+            s.w[2] = s.w[3] = 0.0;
+            s.dwdt[2] = s.dwdt[3] = 0.0;
+            pl.stages.push_back(s);
+        } else {
+            err = "DP5_SE (continuous-time) solver is not implemented yet in the native library";
+            return false;
+        }
+    }
+    pl.step_begin[pl.T] = int(pl.stages.size());
+    pl.state_bytes = size_t(pl.B) * pl.dim * 16;
+    return true;
+}
+
+// Carve the workspace. `chain_slots` = number of intermediate state buffers the backward recompute needs.
+inline size_t carve(Plan& pl, bool need_tape, bool need_backward, int chain_slots) {
+    const size_t E = pl.stages.size();
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off = align_up(off + bytes);
+        return o;
+    };
+    pl.off_stats = take(64 * sizeof(double));
+    pl.off_meta_idx = take(E * 4 * sizeof(int32_t));
+    pl.off_meta_w = take(E * 4 * sizeof(double));
+    pl.off_members = take(2 * kMaxGroups * sizeof(uint64_t));
+    pl.off_coef = take(size_t(pl.Bc) * E * std::max(pl.NC, 1) * sizeof(double));
+    pl.off_udiag = take(pl.dim * sizeof(double));
+    pl.off_buf0 = take(pl.state_bytes);
+    pl.off_buf1 = take(pl.state_bytes);
+    pl.total_fwd = off;
+    pl.off_tape = need_tape ? take(size_t(pl.T + 1) * pl.state_bytes) : 0;
+    pl.chain_slots = chain_slots;
+    if (need_backward) {
+        pl.off_chain = take(size_t(chain_slots > 0 ? chain_slots : 1) * pl.state_bytes);
+        pl.off_ge = take(size_t(pl.Bc) * E * (pl.NC + 1) * sizeof(double));
+        pl.off_wtot = take(pl.dim * sizeof(double));
+        pl.off_meta2 = take(align_up(E * 4 * sizeof(double)) + align_up(E * 3 * sizeof(int32_t)) + align_up(E * sizeof(double)));
+    }
+    return off;
+}
+
+}  // namespace rydiff

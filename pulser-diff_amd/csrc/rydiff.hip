@@ -1,0 +1,1077 @@
+// rydiff.hip — MI355X (gfx950, wave64) kernels + the C ABI declared in include/rydiff.h.
+//
+// The hot path of pulser_diff.backend.TorchEmulator (pulser_diff/backend.py:488-494 calling
+// pulser_diff/hamiltonian.py:526-546 on every solver sub-step) re-designed matrix-free:
+//
+//   K0 k_expand_coeffs   per-exponential effective coefficients from the sampled tables (hamiltonian.py:532-542)
+//   K1 k_factor_*        y = gamma*x + beta*H(t)x : one factor of the product-form propagator (never builds H)
+//   K2 k_expect_diag     <psi|O|psi> for diagonal O (utils.py:79-81), wave-shuffle + LDS reduction
+//   K3 k_factor_bwd_*    adjoint of K1 fused with the gradient contractions (replaces the autograd tape, derivative.py:40,76)
+//   K4 k_inject          cotangent injection  lambda += grad_states + 2*ge*O*psi
+//   K5 k_scatter_grads   per-exponential coefficient gradients -> table / tsave gradients
+//   K6 k_build_udiag / k_ugrad   static interaction diagonal (hamiltonian.py:333-344,368-404) and its gradient
+//
+// No H matrix, no sparse algebra, no accumulator vectors: every factor pass reads the state once and writes it once.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <complex>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rydiff.h"
+#include "plan.hpp"
+#include "poly.hpp"
+
+using namespace rydiff;
+
+// ------------------------------------------------------------------------------------------------
+// error handling
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+static int g_kernel_variant = 0;
+
+static int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess)                                                                          \
+            return fail(RYDIFF_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));               \
+    } while (0)
+
+#define LAUNCH_CHECK()                                                                                 \
+    do {                                                                                               \
+        hipError_t _e = hipGetLastError();                                                             \
+        if (_e != hipSuccess) return fail(RYDIFF_EHIP, std::string("kernel launch: ") + hipGetErrorString(_e)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+struct GroupArgs {
+    int ga, gd;
+    uint32_t amask[kMaxGroups];  // amplitude-index bit masks of the flip groups
+    uint32_t dmask[kMaxGroups];  // amplitude-index bit masks of the detuning groups
+    int dcnt[kMaxGroups];        // qubits per detuning group
+};
+
+struct FactorArgs {
+    const double2* xin;
+    double2* xout;
+    const double* udiag;
+    const double* coef;   // record of this exponential, trajectory 0: c_re[ga], c_im[ga], dcoef[gd]
+    long coef_bstride;    // doubles between trajectories' records (0: shared)
+    uint32_t dim;
+    double gr, gi, br, bi;  // gamma, beta
+    GroupArgs g;
+};
+
+struct FactorBwdArgs {
+    const double2* gin;   // cotangent w.r.t. the factor's output
+    const double2* xin;   // the factor's input (recomputed chain)
+    double2* gout;        // cotangent w.r.t. the factor's input
+    const double* udiag;
+    const double* coef;
+    long coef_bstride;
+    double* ge;           // gradient record of this exponential, trajectory 0: gcre[ga], gcim[ga], gd[gd], gtau
+    long ge_bstride;
+    double* wtot;         // optional [dim]: accumulates Re(beta*conj(g)*x) for the U_ij gradient
+    uint32_t dim;
+    double gr, gi, br, bi;
+    GroupArgs g;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// one value per block: wave shuffle -> LDS -> one global atomic
+__device__ __forceinline__ void block_atomic_add(double v, double* dst, double* lds /* >= 4 doubles */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int w = 0; w < nw; ++w) s += lds[w];
+        unsafeAtomicAdd(dst, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6: static interaction diagonal  U(x) = sum_{i<j} U_ij n_i(x) n_j(x),  n_j = 1 - bit_{N-1-j}(x)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_build_udiag(double* __restrict__ udiag, const double* __restrict__ u_pairs, int N, uint32_t dim) {
+    uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= dim) return;
+    double s = 0.0;
+    int k = 0;
+    for (int i = 0; i < N; ++i) {
+        const bool ni = !((x >> (N - 1 - i)) & 1u);
+        for (int j = i + 1; j < N; ++j, ++k) {
+            const bool nj = !((x >> (N - 1 - j)) & 1u);
+            if (ni && nj) s += u_pairs[k];
+        }
+    }
+    udiag[x] = s;
+}
+
+// g_u[pair] = sum_x n_i n_j wtot[x]
+__global__ void k_ugrad(double* __restrict__ g_u, const double* __restrict__ wtot, int N, uint32_t dim) {
+    __shared__ double lds[8];
+    const int pair = blockIdx.y;
+    int i = 0, rem = pair;
+    while (rem >= N - 1 - i) {
+        rem -= N - 1 - i;
+        ++i;
+    }
+    const int j = i + 1 + rem;
+    const uint32_t mi = 1u << (N - 1 - i), mj = 1u << (N - 1 - j);
+    double s = 0.0;
+    for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < dim; x += gridDim.x * blockDim.x)
+        if (!(x & mi) && !(x & mj)) s += wtot[x];
+    block_atomic_add(s, g_u + pair, lds);
+}
+
+// ------------------------------------------------------------------------------------------------
+// table statistics for the spectral bound (over sample index i, all trajectories):
+//   stats[0] = max_i sum_g |c_g[i]| * count_g         (norm of the flip part, exact for commuting single-qubit terms)
+//   stats[1] = max_i sum_g max(+dcoef_g[i],0)*count_g  stats[2] = max_i sum_g max(-dcoef_g[i],0)*count_g
+//   stats[3] = sum of U_ij
+// all non-negative doubles -> their bit patterns order like unsigned integers (atomicMax on u64).
+// ------------------------------------------------------------------------------------------------
+struct StatsArgs {
+    const double2* amp;
+    const double* det;
+    const double* u_pairs;
+    int n_samples, Ka, Kd, n_pairs, Bc;
+    int ga, gd;
+    uint64_t amem[kMaxGroups], dmem[kMaxGroups];
+    int acnt[kMaxGroups], dcnt[kMaxGroups];
+};
+
+__global__ void k_table_stats(unsigned long long* __restrict__ stats, StatsArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i < a.n_samples) {
+        double flip = 0.0, dpos = 0.0, dneg = 0.0;
+        for (int g = 0; g < a.ga; ++g) {
+            double re = 0.0, im = 0.0;
+            for (int k = 0; k < a.Ka; ++k)
+                if (a.amem[g] >> k & 1ull) {
+                    double2 v = a.amp[(size_t(b) * a.Ka + k) * a.n_samples + i];
+                    re += v.x;
+                    im += v.y;
+                }
+            flip += sqrt(re * re + im * im) * a.acnt[g];
+        }
+        for (int g = 0; g < a.gd; ++g) {
+            double d = 0.0;
+            for (int k = 0; k < a.Kd; ++k)
+                if (a.dmem[g] >> k & 1ull) d += 2.0 * a.det[(size_t(b) * a.Kd + k) * a.n_samples + i];
+            if (d > 0.0) dpos += d * a.dcnt[g];
+            else dneg += -d * a.dcnt[g];
+        }
+        atomicMax(stats + 0, (unsigned long long)__double_as_longlong(flip));
+        atomicMax(stats + 1, (unsigned long long)__double_as_longlong(dpos));
+        atomicMax(stats + 2, (unsigned long long)__double_as_longlong(dneg));
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        double s = 0.0;
+        for (int k = 0; k < a.n_pairs; ++k) s += fabs(a.u_pairs[k]);
+        stats[3] = (unsigned long long)__double_as_longlong(s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0: effective coefficients of every exponential.  record = c_re[ga], c_im[ga], dcoef[gd]
+//   c_g   = sum_{terms k in group g} sum_q w[e][q] * amp_k[idx[e][q]]        (hamiltonian.py:542)
+//   dcoef = 2 * sum_{terms k in group g} sum_q w[e][q] * det_k[idx[e][q]]    (hamiltonian.py:538-540)
+// ------------------------------------------------------------------------------------------------
+struct ExpandArgs {
+    const double2* amp;
+    const double* det;
+    const int32_t* idx;  // [E][4]
+    const double* w;     // [E][4]
+    double* coef;        // [Bc][E][NC]
+    int E, n_samples, Ka, Kd, NC, ga, gd;
+    uint64_t amem[kMaxGroups], dmem[kMaxGroups];
+};
+
+__global__ void k_expand_coeffs(ExpandArgs a) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (e >= a.E) return;
+    double* rec = a.coef + (size_t(b) * a.E + e) * a.NC;
+    int idx[4];
+    double w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        idx[q] = a.idx[e * 4 + q];
+        w[q] = a.w[e * 4 + q];
+    }
+    for (int g = 0; g < a.ga; ++g) {
+        double re = 0.0, im = 0.0;
+        for (int k = 0; k < a.Ka; ++k)
+            if (a.amem[g] >> k & 1ull) {
+                const double2* t = a.amp + (size_t(b) * a.Ka + k) * a.n_samples;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (w[q] != 0.0) {
+                        re += w[q] * t[idx[q]].x;
+                        im += w[q] * t[idx[q]].y;
+                    }
+            }
+        rec[g] = re;
+        rec[a.ga + g] = im;
+    }
+    for (int g = 0; g < a.gd; ++g) {
+        double d = 0.0;
+        for (int k = 0; k < a.Kd; ++k)
+            if (a.dmem[g] >> k & 1ull) {
+                const double* t = a.det + (size_t(b) * a.Kd + k) * a.n_samples;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (w[q] != 0.0) d += w[q] * t[idx[q]];
+            }
+        rec[2 * a.ga + g] = 2.0 * d;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 (direct variant): one amplitude per thread, partners fetched from global memory (L2 / Infinity Cache).
+//   y[x] = (gamma + beta*d(x)) psi[x] + beta * sum_g [ c_g * sum_{j in g, bit_j(x)=1} psi[x^m_j]
+//                                                   + conj(c_g) * sum_{j in g, bit_j(x)=0} psi[x^m_j] ]
+//   d(x) = U(x) + sum_g dcoef_g * (#qubits of g in |r>)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double diag_value(const double* __restrict__ udiag, const double* __restrict__ cf, const GroupArgs& g,
+                                             uint32_t x) {
+    double d = udiag[x];
+    for (int q = 0; q < g.gd; ++q) d += cf[2 * g.ga + q] * double(g.dcnt[q] - __popc(x & g.dmask[q]));
+    return d;
+}
+
+__global__ __launch_bounds__(256) void k_factor_direct(FactorArgs a) {
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    if (x >= a.dim) return;
+    const size_t boff = size_t(blockIdx.y) * a.dim;
+    const double2* __restrict__ xin = a.xin + boff;
+    const double* __restrict__ cf = a.coef + blockIdx.y * a.coef_bstride;
+    const double d = diag_value(a.udiag, cf, a.g, x);
+    const double2 v = xin[x];
+    const double dr = a.gr + a.br * d, di = a.gi + a.bi * d;
+    double ar = dr * v.x - di * v.y, ai = dr * v.y + di * v.x;
+    for (int q = 0; q < a.g.ga; ++q) {
+        double s1r = 0.0, s1i = 0.0, s0r = 0.0, s0i = 0.0;
+        uint32_t m = a.g.amask[q];
+        while (m) {
+            const uint32_t bit = m & (0u - m);
+            m ^= bit;
+            const double2 p = xin[x ^ bit];
+            if (x & bit) {
+                s1r += p.x;
+                s1i += p.y;
+            } else {
+                s0r += p.x;
+                s0i += p.y;
+            }
+        }
+        const double cr = cf[q], ci = cf[a.g.ga + q];
+        // beta*c and beta*conj(c)
+        const double b1r = a.br * cr - a.bi * ci, b1i = a.br * ci + a.bi * cr;
+        const double b0r = a.br * cr + a.bi * ci, b0i = -a.br * ci + a.bi * cr;
+        ar += b1r * s1r - b1i * s1i + b0r * s0r - b0i * s0i;
+        ai += b1r * s1i + b1i * s1r + b0r * s0i + b0i * s0r;
+    }
+    a.xout[boff + x] = make_double2(ar, ai);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3 (direct variant): adjoint of one factor + gradient contractions.
+//   gout = (conj(gamma) + conj(beta) H) gin
+//   dL/dRe c_g += Re( beta * sum_x conj(gin[x]) * (partner sums of xin) )      dL/dIm c_g likewise with +-i
+//   dL/ddcoef_g += sum_x cnt_g(x) * Re( beta conj(gin[x]) xin[x] )
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_factor_bwd_direct(FactorBwdArgs a) {
+    __shared__ double lds[8];
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    const bool live = x < a.dim;
+    const size_t boff = size_t(blockIdx.y) * a.dim;
+    const double2* __restrict__ gin = a.gin + boff;
+    const double2* __restrict__ xin = a.xin + boff;
+    const double* __restrict__ cf = a.coef + blockIdx.y * a.coef_bstride;
+    double* __restrict__ ge = a.ge + blockIdx.y * a.ge_bstride;
+    const uint32_t xs = live ? x : 0u;
+    const double d = diag_value(a.udiag, cf, a.g, xs);
+    double2 gy = gin[xs];
+    double2 xi = xin[xs];
+    if (!live) {
+        gy = make_double2(0.0, 0.0);
+        xi = make_double2(0.0, 0.0);
+    }
+    // adjoint matvec with conj(gamma), conj(beta)
+    const double dr = a.gr + a.br * d, di = -(a.gi + a.bi * d);
+    double ar = dr * gy.x - di * gy.y, ai = dr * gy.y + di * gy.x;
+    // a_ = beta * conj(gy)
+    const double pr = a.br * gy.x + a.bi * gy.y, pi = a.bi * gy.x - a.br * gy.y;
+    const double r = pr * xi.x - pi * xi.y;  // Re(beta conj(gy) xi)
+    if (a.wtot && live) unsafeAtomicAdd(a.wtot + x, r);
+    for (int q = 0; q < a.g.ga; ++q) {
+        double s1r = 0.0, s1i = 0.0, s0r = 0.0, s0i = 0.0;  // partner sums of gin (for the matvec)
+        double t1r = 0.0, t1i = 0.0, t0r = 0.0, t0i = 0.0;  // partner sums of xin (for the contraction)
+        uint32_t m = a.g.amask[q];
+        while (m) {
+            const uint32_t bit = m & (0u - m);
+            m ^= bit;
+            const double2 p = gin[xs ^ bit];
+            const double2 t = xin[xs ^ bit];
+            if (xs & bit) {
+                s1r += p.x; s1i += p.y; t1r += t.x; t1i += t.y;
+            } else {
+                s0r += p.x; s0i += p.y; t0r += t.x; t0i += t.y;
+            }
+        }
+        const double cr = cf[q], ci = cf[a.g.ga + q];
+        // conj(beta)*c and conj(beta)*conj(c)
+        const double b1r = a.br * cr + a.bi * ci, b1i = a.br * ci - a.bi * cr;
+        const double b0r = a.br * cr - a.bi * ci, b0i = -a.br * ci - a.bi * cr;
+        ar += b1r * s1r - b1i * s1i + b0r * s0r - b0i * s0i;
+        ai += b1r * s1i + b1i * s1r + b0r * s0i + b0i * s0r;
+        // S1 = a_*t1, S0 = a_*t0 ; g_cre = Re(S1+S0), g_cim = -Im(S1-S0)
+        double gre = 0.0, gim = 0.0;
+        if (live) {
+            const double S1r = pr * t1r - pi * t1i, S1i = pr * t1i + pi * t1r;
+            const double S0r = pr * t0r - pi * t0i, S0i = pr * t0i + pi * t0r;
+            gre = S1r + S0r;
+            gim = -(S1i - S0i);
+        }
+        block_atomic_add(gre, ge + q, lds);
+        block_atomic_add(gim, ge + a.g.ga + q, lds);
+    }
+    for (int q = 0; q < a.g.gd; ++q) {
+        const double v = live ? r * double(a.g.dcnt[q] - __popc(x & a.g.dmask[q])) : 0.0;
+        block_atomic_add(v, ge + 2 * a.g.ga + q, lds);
+    }
+    if (live) a.gout[boff + x] = make_double2(ar, ai);
+}
+
+// dL/dtau of one exponential:  Re< g, -i H x >  = Im( sum_x conj(g[x]) (H x)[x] )
+struct DotHArgs {
+    const double2* g;
+    const double2* x;
+    const double* udiag;
+    const double* coef;
+    long coef_bstride;
+    double* out;  // ge record + NC (gtau slot), trajectory 0
+    long out_bstride;
+    uint32_t dim;
+    GroupArgs gr;
+};
+
+__global__ __launch_bounds__(256) void k_dot_hx(DotHArgs a) {
+    __shared__ double lds[8];
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    const bool live = x < a.dim;
+    const uint32_t xs = live ? x : 0u;
+    const size_t boff = size_t(blockIdx.y) * a.dim;
+    const double2* __restrict__ xin = a.x + boff;
+    const double* __restrict__ cf = a.coef + blockIdx.y * a.coef_bstride;
+    const double d = diag_value(a.udiag, cf, a.gr, xs);
+    const double2 v = xin[xs];
+    double hr = d * v.x, hi = d * v.y;
+    for (int q = 0; q < a.gr.ga; ++q) {
+        double s1r = 0.0, s1i = 0.0, s0r = 0.0, s0i = 0.0;
+        uint32_t m = a.gr.amask[q];
+        while (m) {
+            const uint32_t bit = m & (0u - m);
+            m ^= bit;
+            const double2 p = xin[xs ^ bit];
+            if (xs & bit) { s1r += p.x; s1i += p.y; } else { s0r += p.x; s0i += p.y; }
+        }
+        const double cr = cf[q], ci = cf[a.gr.ga + q];
+        hr += cr * s1r - ci * s1i + cr * s0r + ci * s0i;
+        hi += cr * s1i + ci * s1r + cr * s0i - ci * s0r;
+    }
+    const double2 g = (a.g + boff)[xs];
+    // Im(conj(g) * h) = g.x*hi - g.y*hr
+    const double val = live ? (g.x * hi - g.y * hr) : 0.0;
+    block_atomic_add(val, a.out + blockIdx.y * a.out_bstride, lds);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: expectation values of diagonal observables, one launch per saved state.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_expect_diag(const double2* __restrict__ psi, const double* __restrict__ obs,
+                                                     double* __restrict__ out /* [n_obs][n_tsave][B] */, int n_obs,
+                                                     int n_tsave, int k, int B, uint32_t dim) {
+    __shared__ double lds[8];
+    const int b = blockIdx.y;
+    const double2* __restrict__ p = psi + size_t(b) * dim;
+    for (int o = 0; o < n_obs; ++o) {
+        double s = 0.0;
+        for (uint32_t x = blockIdx.x * 256u + threadIdx.x; x < dim; x += gridDim.x * 256u) {
+            const double2 v = p[x];
+            s += obs[size_t(o) * dim + x] * (v.x * v.x + v.y * v.y);
+        }
+        block_atomic_add(s, out + (size_t(o) * n_tsave + k) * B + b, lds);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: lambda[b][x] (+)= grad_states[k][b][x] + 2 * sum_o ge[o][k][b] * obs[o][x] * psi_k[b][x]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_inject(double2* __restrict__ lam, const double2* __restrict__ gstate,
+                                                const double2* __restrict__ psi, const double* __restrict__ obs,
+                                                const double* __restrict__ gexp, int n_obs, int n_tsave, int k, int B,
+                                                uint32_t dim, int overwrite) {
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    if (x >= dim) return;
+    const int b = blockIdx.y;
+    const size_t o_ = size_t(b) * dim + x;
+    double2 acc = overwrite ? make_double2(0.0, 0.0) : lam[o_];
+    if (gstate) {
+        const double2 g = gstate[o_];
+        acc.x += g.x;
+        acc.y += g.y;
+    }
+    if (gexp && n_obs > 0) {
+        double wsum = 0.0;
+        for (int o = 0; o < n_obs; ++o) wsum += gexp[(size_t(o) * n_tsave + k) * B + b] * obs[size_t(o) * dim + x];
+        const double2 v = psi[o_];
+        acc.x += 2.0 * wsum * v.x;
+        acc.y += 2.0 * wsum * v.y;
+    }
+    lam[o_] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: scatter per-exponential coefficient gradients back onto the sampled tables and tsave.
+// one thread per (exponential, trajectory); atomics because several exponentials touch one sample.
+// ------------------------------------------------------------------------------------------------
+struct ScatterArgs {
+    const double* ge;       // [Bc][E][NC+1]
+    const int32_t* idx;     // [E][4]
+    const double* w;        // [E][4]
+    const double* dwdt;     // [E][4]
+    const int32_t* tinfo;   // [E][3] = tnode, t_hi, t_lo
+    const double* tscale;   // [E]
+    const double2* amp;     // tables (for d coef / d t)
+    const double* det;
+    double2* g_amp;
+    double* g_det;
+    double* g_tsave;
+    int E, n_samples, Ka, Kd, NC, ga, gd;
+    uint64_t amem[kMaxGroups], dmem[kMaxGroups];
+};
+
+__global__ void k_scatter_grads(ScatterArgs a) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (e >= a.E) return;
+    const double* rec = a.ge + (size_t(b) * a.E + e) * (a.NC + 1);
+    double dLdt = 0.0;
+    for (int k = 0; k < a.Ka; ++k) {
+        double gr = 0.0, gi = 0.0;
+        for (int g = 0; g < a.ga; ++g)
+            if (a.amem[g] >> k & 1ull) {
+                gr += rec[g];
+                gi += rec[a.ga + g];
+            }
+        const double2* t = a.amp + (size_t(b) * a.Ka + k) * a.n_samples;
+        for (int q = 0; q < 4; ++q) {
+            const double w = a.w[e * 4 + q], dw = a.dwdt[e * 4 + q];
+            const int i = a.idx[e * 4 + q];
+            if (a.g_amp && w != 0.0) {
+                double* dst = reinterpret_cast<double*>(a.g_amp + (size_t(b) * a.Ka + k) * a.n_samples + i);
+                unsafeAtomicAdd(dst, w * gr);
+                unsafeAtomicAdd(dst + 1, w * gi);
+            }
+            if (dw != 0.0) dLdt += dw * (gr * t[i].x + gi * t[i].y);
+        }
+    }
+    for (int k = 0; k < a.Kd; ++k) {
+        double gd = 0.0;
+        for (int g = 0; g < a.gd; ++g)
+            if (a.dmem[g] >> k & 1ull) gd += rec[2 * a.ga + g];
+        const double* t = a.det + (size_t(b) * a.Kd + k) * a.n_samples;
+        for (int q = 0; q < 4; ++q) {
+            const double w = a.w[e * 4 + q], dw = a.dwdt[e * 4 + q];
+            const int i = a.idx[e * 4 + q];
+            if (a.g_det && w != 0.0) unsafeAtomicAdd(a.g_det + (size_t(b) * a.Kd + k) * a.n_samples + i, 2.0 * w * gd);
+            if (dw != 0.0) dLdt += dw * 2.0 * gd * t[i];
+        }
+    }
+    if (a.g_tsave) {
+        const int tnode = a.tinfo[e * 3 + 0], thi = a.tinfo[e * 3 + 1], tlo = a.tinfo[e * 3 + 2];
+        const double gtau = rec[a.NC] * a.tscale[e];
+        unsafeAtomicAdd(a.g_tsave + tnode, dLdt);
+        unsafeAtomicAdd(a.g_tsave + thi, gtau);
+        unsafeAtomicAdd(a.g_tsave + tlo, -gtau);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct Runtime {
+    Plan pl;
+    PolyDesign poly;
+    double sigma = 0.0, width = 1.0, rho_design = 1.0;
+    int64_t total_factors = 0;
+    int max_step_factors = 0;
+    GroupArgs garg{};
+};
+
+std::mutex g_poly_mutex;
+std::vector<PolyDesign> g_poly_cache;
+
+PolyDesign cached_design(double rho, double tol) {
+    std::lock_guard<std::mutex> lk(g_poly_mutex);
+    for (const auto& d : g_poly_cache)
+        if (d.rho == rho && d.tol == tol) return d;
+    PolyDesign d = design_polynomial(rho, tol);
+    if (g_poly_cache.size() > 64) g_poly_cache.clear();
+    g_poly_cache.push_back(d);
+    return d;
+}
+
+void fill_group_args(const Plan& pl, GroupArgs& g) {
+    g.ga = pl.ga.n;
+    g.gd = pl.gd.n;
+    for (int q = 0; q < pl.ga.n; ++q) g.amask[q] = pl.ga.amp_index_mask[q];
+    for (int q = 0; q < pl.gd.n; ++q) {
+        g.dmask[q] = pl.gd.amp_index_mask[q];
+        g.dcnt[q] = pl.gd.count[q];
+    }
+}
+
+// apply spectral bounds: sub-steps, design rho, polynomial, factor counts
+int finish_runtime(Runtime& rt, double lo, double hi) {
+    Plan& pl = rt.pl;
+    if (!(hi >= lo) || !std::isfinite(hi) || !std::isfinite(lo)) return fail(RYDIFF_EINVAL, "non-finite spectral bounds (NaN/Inf in the coefficient tables?)");
+    rt.sigma = 0.5 * (hi + lo);
+    rt.width = std::max(0.5 * (hi - lo), 1e-9);
+    double rho_d = 1e-6;
+    for (auto& s : pl.stages) {
+        const double rho = s.tau * rt.width;
+        s.nsub = std::max(1, int(std::ceil(rho / kRhoCap)));
+        rho_d = std::max(rho_d, rho / s.nsub);
+    }
+    // quantise rho upward a little so that optimisation epochs with slowly drifting tables reuse the cached design
+    const double q = std::pow(2.0, std::ceil(std::log2(rho_d) * 16.0) / 16.0);
+    rt.rho_design = q;
+    rt.poly = cached_design(rt.rho_design, pl.tol);
+    if (rt.poly.degree < 1 || rt.poly.roots.empty()) return fail(RYDIFF_EINVAL, "polynomial design failed");
+    rt.total_factors = 0;
+    rt.max_step_factors = 0;
+    for (int k = 0; k < pl.T; ++k) {
+        int f = 0;
+        for (int e = pl.step_begin[k]; e < pl.step_begin[k + 1]; ++e) f += pl.stages[e].nsub * rt.poly.degree;
+        rt.total_factors += f;
+        rt.max_step_factors = std::max(rt.max_step_factors, f);
+    }
+    fill_group_args(pl, rt.garg);
+    return RYDIFF_OK;
+}
+
+int run_stats(const RydProblem* p, const Plan& pl, void* scratch, hipStream_t stream, double& lo, double& hi) {
+    StatsArgs sa{};
+    sa.amp = static_cast<const double2*>(p->amp_tables);
+    sa.det = p->det_tables;
+    sa.u_pairs = p->u_pairs;
+    sa.n_samples = pl.n_samples;
+    sa.Ka = pl.Ka;
+    sa.Kd = pl.Kd;
+    sa.n_pairs = pl.N * (pl.N - 1) / 2;
+    sa.Bc = pl.Bc;
+    sa.ga = pl.ga.n;
+    sa.gd = pl.gd.n;
+    for (int g = 0; g < pl.ga.n; ++g) {
+        sa.amem[g] = pl.ga.members[g];
+        sa.acnt[g] = pl.ga.count[g];
+    }
+    for (int g = 0; g < pl.gd.n; ++g) {
+        sa.dmem[g] = pl.gd.members[g];
+        sa.dcnt[g] = pl.gd.count[g];
+    }
+    HIP_TRY(hipMemsetAsync(scratch, 0, 8 * sizeof(double), stream));
+    const int ns = std::max(pl.n_samples, 1);
+    dim3 grid((ns + 127) / 128, pl.Bc);
+    hipLaunchKernelGGL(k_table_stats, grid, dim3(128), 0, stream, static_cast<unsigned long long*>(scratch), sa);
+    LAUNCH_CHECK();
+    double host[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(host, scratch, sizeof(host), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    // interpolation weights: KRYLOV_SE uses convex combinations (sum |w| = 1); keep the general bound
+    double wsum = 1.0;
+    for (const auto& s : pl.stages) {
+        double a = 0.0;
+        for (int q = 0; q < 4; ++q) a += std::fabs(s.w[q]);
+        wsum = std::max(wsum, a);
+    }
+    hi = host[3] + wsum * (host[1] + host[0]);
+    lo = -wsum * (host[2] + host[0]);
+    return RYDIFF_OK;
+}
+
+void fill_info(const Runtime& rt, double lo, double hi, size_t ws, RydPlanInfo* info) {
+    info->spectral_lo = lo;
+    info->spectral_hi = hi;
+    info->rho_design = rt.rho_design;
+    info->degree = rt.poly.degree;
+    info->n_stages = int(rt.pl.stages.size());
+    info->max_step_factors = rt.max_step_factors;
+    info->reserved = 0;
+    info->total_factors = rt.total_factors;
+    info->workspace_bytes = ws;
+}
+
+// common prologue of forward / backward: plan, (optional) stats, carve, upload metadata, expand coefficients, udiag
+int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_t workspace_bytes, bool need_tape,
+            bool need_backward, hipStream_t stream, Runtime& rt) {
+    std::string err;
+    if (!build_plan(p, rt.pl, err)) return fail(err.find("not implemented") != std::string::npos ? RYDIFF_ENOTIMPL : RYDIFF_EINVAL, err);
+    if (!workspace) return fail(RYDIFF_EINVAL, "null workspace");
+    double lo, hi;
+    if (info) {
+        lo = info->spectral_lo;
+        hi = info->spectral_hi;
+    } else {
+        if (workspace_bytes < RYDIFF_PLAN_SCRATCH_BYTES) return fail(RYDIFF_EWORKSPACE, "workspace too small");
+        int rc = run_stats(p, rt.pl, workspace, stream, lo, hi);
+        if (rc) return rc;
+    }
+    int rc = finish_runtime(rt, lo, hi);
+    if (rc) return rc;
+    Plan& pl = rt.pl;
+    const size_t need = carve(pl, need_tape, need_backward, std::max(rt.max_step_factors - 1, 1));
+    if (workspace_bytes < need)
+        return fail(RYDIFF_EWORKSPACE, "workspace too small: need " + std::to_string(need) + " bytes, got " + std::to_string(workspace_bytes));
+    char* ws = static_cast<char*>(workspace);
+    const size_t E = pl.stages.size();
+    // stage metadata -> device (pageable host memory: the runtime stages it before returning)
+    std::vector<int32_t> idx(E * 4);
+    std::vector<double> w(E * 4);
+    for (size_t e = 0; e < E; ++e)
+        for (int q = 0; q < 4; ++q) {
+            idx[e * 4 + q] = pl.stages[e].idx[q];
+            w[e * 4 + q] = pl.stages[e].w[q];
+        }
+    HIP_TRY(hipMemcpyAsync(ws + pl.off_meta_idx, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(ws + pl.off_meta_w, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));  // idx/w are stack vectors: make sure the copies are done before they die
+    if (pl.NC > 0) {
+        ExpandArgs ea{};
+        ea.amp = static_cast<const double2*>(p->amp_tables);
+        ea.det = p->det_tables;
+        ea.idx = reinterpret_cast<const int32_t*>(ws + pl.off_meta_idx);
+        ea.w = reinterpret_cast<const double*>(ws + pl.off_meta_w);
+        ea.coef = reinterpret_cast<double*>(ws + pl.off_coef);
+        ea.E = int(E);
+        ea.n_samples = pl.n_samples;
+        ea.Ka = pl.Ka;
+        ea.Kd = pl.Kd;
+        ea.NC = pl.NC;
+        ea.ga = pl.ga.n;
+        ea.gd = pl.gd.n;
+        for (int g = 0; g < pl.ga.n; ++g) ea.amem[g] = pl.ga.members[g];
+        for (int g = 0; g < pl.gd.n; ++g) ea.dmem[g] = pl.gd.members[g];
+        dim3 grid((unsigned(E) + 127) / 128, pl.Bc);
+        hipLaunchKernelGGL(k_expand_coeffs, grid, dim3(128), 0, stream, ea);
+        LAUNCH_CHECK();
+    }
+    double* udiag = reinterpret_cast<double*>(ws + pl.off_udiag);
+    if (pl.N > 1) {
+        hipLaunchKernelGGL(k_build_udiag, dim3((pl.dim + 255) / 256), dim3(256), 0, stream, udiag, p->u_pairs, pl.N, uint32_t(pl.dim));
+        LAUNCH_CHECK();
+    } else {
+        HIP_TRY(hipMemsetAsync(udiag, 0, pl.dim * sizeof(double), stream));
+    }
+    return RYDIFF_OK;
+}
+
+struct FactorScalars {
+    double gr, gi, br, bi;
+};
+
+// scalars of factor f of one sub-exponential of duration tau_sub
+FactorScalars factor_scalars(const Runtime& rt, double tau_sub, int f) {
+    using cd = std::complex<double>;
+    const cd z = rt.poly.roots[f];
+    // p(x) ~ exp(-i*rho_d*x) with x = tau_sub*(H - sigma)/rho_d, spectrum of x inside [-1,1] because
+    // tau_sub*width <= rho_d.  One factor: (1 - x/z) = [1 + tau_sub*sigma/(rho_d z)] - [tau_sub/(rho_d z)] H
+    const cd denom = rt.rho_design * z;
+    cd beta = -tau_sub / denom;
+    cd gamma = cd(1.0, 0.0) + tau_sub * rt.sigma / denom;
+    if (f == rt.poly.degree - 1) {
+        const cd kappa = std::exp(cd(0.0, -tau_sub * rt.sigma)) * rt.poly.p0;
+        beta *= kappa;
+        gamma *= kappa;
+    }
+    return {gamma.real(), gamma.imag(), beta.real(), beta.imag()};
+}
+
+struct ChainItem {
+    int stage;
+    FactorScalars s;
+};
+
+void build_step_chain(const Runtime& rt, int k, std::vector<ChainItem>& chain) {
+    chain.clear();
+    const Plan& pl = rt.pl;
+    for (int e = pl.step_begin[k]; e < pl.step_begin[k + 1]; ++e) {
+        const Stage& st = pl.stages[e];
+        const double tau_sub = st.tau / st.nsub;
+        for (int s = 0; s < st.nsub; ++s)
+            for (int f = 0; f < rt.poly.degree; ++f) chain.push_back({e, factor_scalars(rt, tau_sub, f)});
+    }
+}
+
+int launch_factor(const Runtime& rt, char* ws, const double2* xin, double2* xout, int stage, const FactorScalars& s, hipStream_t stream) {
+    const Plan& pl = rt.pl;
+    FactorArgs fa{};
+    fa.xin = xin;
+    fa.xout = xout;
+    fa.udiag = reinterpret_cast<const double*>(ws + pl.off_udiag);
+    fa.coef = reinterpret_cast<const double*>(ws + pl.off_coef) + size_t(stage) * pl.NC;
+    fa.coef_bstride = pl.Bc > 1 ? long(pl.stages.size()) * pl.NC : 0;
+    fa.dim = uint32_t(pl.dim);
+    fa.gr = s.gr;
+    fa.gi = s.gi;
+    fa.br = s.br;
+    fa.bi = s.bi;
+    fa.g = rt.garg;
+    dim3 grid(unsigned((pl.dim + 255) / 256), pl.B);
+    hipLaunchKernelGGL(k_factor_direct, grid, dim3(256), 0, stream, fa);
+    LAUNCH_CHECK();
+    return RYDIFF_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* rydiff_last_error(void) { return g_last_error.c_str(); }
+const char* rydiff_version(void) { return "rydiff 0.1 (gfx950)"; }
+
+int rydiff_set_kernel_variant(int variant) {
+    if (variant < 0 || variant > 2) return fail(RYDIFF_EINVAL, "kernel variant must be 0, 1 or 2");
+    g_kernel_variant = variant;
+    return RYDIFF_OK;
+}
+
+int rydiff_design_polynomial(double rho, double tol, int max_degree, int* degree, double* roots_reim, double* p0_reim, double* max_err) {
+    if (!(rho > 0.0) || !degree || !roots_reim || max_degree < 1) return fail(RYDIFF_EINVAL, "bad arguments");
+    PolyDesign d = design_polynomial(rho, tol, max_degree);
+    if (d.degree < 1) return fail(RYDIFF_EINVAL, "polynomial design failed");
+    *degree = d.degree;
+    for (int i = 0; i < d.degree; ++i) {
+        roots_reim[2 * i] = d.roots[i].real();
+        roots_reim[2 * i + 1] = d.roots[i].imag();
+    }
+    if (p0_reim) {
+        p0_reim[0] = d.p0.real();
+        p0_reim[1] = d.p0.imag();
+    }
+    if (max_err) *max_err = d.max_err;
+    return RYDIFF_OK;
+}
+
+int rydiff_plan(const RydProblem* p, int need_tape, int need_backward, void* scratch, void* stream_, RydPlanInfo* info) {
+    if (!info || !scratch) return fail(RYDIFF_EINVAL, "null info or scratch");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Runtime rt;
+    std::string err;
+    if (!build_plan(p, rt.pl, err)) return fail(err.find("not implemented") != std::string::npos ? RYDIFF_ENOTIMPL : RYDIFF_EINVAL, err);
+    double lo, hi;
+    int rc = run_stats(p, rt.pl, scratch, stream, lo, hi);
+    if (rc) return rc;
+    rc = finish_runtime(rt, lo, hi);
+    if (rc) return rc;
+    const size_t ws = carve(rt.pl, need_tape != 0, need_backward != 0, std::max(rt.max_step_factors - 1, 1));
+    fill_info(rt, lo, hi, ws, info);
+    return RYDIFF_OK;
+}
+
+int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi0, void* states_out, double* expect_out,
+                   void* workspace, size_t workspace_bytes, int need_tape, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!psi0) return fail(RYDIFF_EINVAL, "null psi0");
+    Runtime rt;
+    int rc = prepare(p, info, workspace, workspace_bytes, need_tape != 0 && !states_out, false, stream, rt);
+    if (rc) return rc;
+    const Plan& pl = rt.pl;
+    char* ws = static_cast<char*>(workspace);
+    const size_t sv = size_t(pl.B) * pl.dim;  // complex elements per saved state
+    double2* buf[2] = {reinterpret_cast<double2*>(ws + pl.off_buf0), reinterpret_cast<double2*>(ws + pl.off_buf1)};
+    double2* tape = states_out ? static_cast<double2*>(states_out)
+                               : (need_tape ? reinterpret_cast<double2*>(ws + pl.off_tape) : nullptr);
+    const double2* cur = static_cast<const double2*>(psi0);
+    if (tape) {
+        HIP_TRY(hipMemcpyAsync(tape, psi0, pl.state_bytes, hipMemcpyDeviceToDevice, stream));
+        cur = tape;
+    }
+    const double* obs = p->obs_diag;
+    const bool want_exp = expect_out && pl.n_obs > 0;
+    const unsigned red_blocks = unsigned(std::min<size_t>((pl.dim + 255) / 256, 1024));
+    if (want_exp) {
+        HIP_TRY(hipMemsetAsync(expect_out, 0, size_t(pl.n_obs) * (pl.T + 1) * pl.B * sizeof(double), stream));
+        hipLaunchKernelGGL(k_expect_diag, dim3(red_blocks, pl.B), dim3(256), 0, stream, cur, obs, expect_out, pl.n_obs, pl.T + 1, 0, pl.B, uint32_t(pl.dim));
+        LAUNCH_CHECK();
+    }
+    std::vector<ChainItem> chain;
+    int pp = 0;
+    for (int k = 0; k < pl.T; ++k) {
+        build_step_chain(rt, k, chain);
+        for (size_t i = 0; i < chain.size(); ++i) {
+            const bool last = (i + 1 == chain.size());
+            double2* dst;
+            if (last && tape) dst = tape + size_t(k + 1) * sv;
+            else {
+                dst = buf[pp];
+                if (dst == cur) dst = buf[pp ^ 1];
+                pp ^= 1;
+            }
+            rc = launch_factor(rt, ws, cur, dst, chain[i].stage, chain[i].s, stream);
+            if (rc) return rc;
+            cur = dst;
+        }
+        if (want_exp) {
+            hipLaunchKernelGGL(k_expect_diag, dim3(red_blocks, pl.B), dim3(256), 0, stream, cur, obs, expect_out, pl.n_obs, pl.T + 1, k + 1, pl.B, uint32_t(pl.dim));
+            LAUNCH_CHECK();
+        }
+    }
+    if (!tape && states_out == nullptr && need_tape == 0) {
+        // nothing else to do: caller only wanted expectation values
+    }
+    return RYDIFF_OK;
+}
+
+int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* states, const void* grad_states,
+                    const double* grad_expect, void* g_amp, double* g_det, double* g_u, double* g_tsave, void* g_psi0,
+                    void* workspace, size_t workspace_bytes, int need_tape, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!states && !need_tape) return fail(RYDIFF_EINVAL, "backward needs the trajectory: pass states or use the workspace tape");
+    Runtime rt;
+    int rc = prepare(p, info, workspace, workspace_bytes, need_tape != 0 && !states, true, stream, rt);
+    if (rc) return rc;
+    const Plan& pl = rt.pl;
+    char* ws = static_cast<char*>(workspace);
+    const size_t sv = size_t(pl.B) * pl.dim;
+    const size_t E = pl.stages.size();
+    const double2* tape = states ? static_cast<const double2*>(states) : reinterpret_cast<const double2*>(ws + pl.off_tape);
+    double2* lam[2] = {reinterpret_cast<double2*>(ws + pl.off_buf0), reinterpret_cast<double2*>(ws + pl.off_buf1)};
+    double2* chainbuf = reinterpret_cast<double2*>(ws + pl.off_chain);
+    double* ge = reinterpret_cast<double*>(ws + pl.off_ge);
+    double* wtot = g_u ? reinterpret_cast<double*>(ws + pl.off_wtot) : nullptr;
+    const double* udiag = reinterpret_cast<const double*>(ws + pl.off_udiag);
+    const double* coef = reinterpret_cast<const double*>(ws + pl.off_coef);
+    const long coef_bstride = pl.Bc > 1 ? long(E) * pl.NC : 0;
+    const long ge_bstride = pl.Bc > 1 ? long(E) * (pl.NC + 1) : 0;
+    const double2* gst = static_cast<const double2*>(grad_states);
+    const double* obs = p->obs_diag;
+    const bool have_gexp = grad_expect && pl.n_obs > 0;
+
+    HIP_TRY(hipMemsetAsync(ge, 0, size_t(pl.Bc) * E * (pl.NC + 1) * sizeof(double), stream));
+    if (wtot) HIP_TRY(hipMemsetAsync(wtot, 0, pl.dim * sizeof(double), stream));
+    dim3 grid(unsigned((pl.dim + 255) / 256), pl.B);
+    int cl = 0;
+    // cotangent at the final time
+    hipLaunchKernelGGL(k_inject, grid, dim3(256), 0, stream, lam[cl], gst ? gst + size_t(pl.T) * sv : nullptr,
+                       tape + size_t(pl.T) * sv, obs, have_gexp ? grad_expect : nullptr, pl.n_obs, pl.T + 1, pl.T, pl.B,
+                       uint32_t(pl.dim), 1);
+    LAUNCH_CHECK();
+
+    std::vector<ChainItem> chain;
+    std::vector<const double2*> xs;
+    for (int k = pl.T - 1; k >= 0; --k) {
+        build_step_chain(rt, k, chain);
+        const int M = int(chain.size());
+        if (M - 1 > pl.chain_slots) return fail(RYDIFF_EWORKSPACE, "internal: chain buffers too small");
+        // recompute the factor inputs x_0 .. x_{M-1}
+        xs.assign(M + 1, nullptr);
+        xs[0] = tape + size_t(k) * sv;
+        for (int i = 1; i < M; ++i) {
+            double2* dst = chainbuf + size_t(i - 1) * sv;
+            rc = launch_factor(rt, ws, xs[i - 1], dst, chain[i - 1].stage, chain[i - 1].s, stream);
+            if (rc) return rc;
+            xs[i] = dst;
+        }
+        xs[M] = tape + size_t(k + 1) * sv;
+        for (int i = M; i >= 1; --i) {
+            const ChainItem& it = chain[i - 1];
+            // dL/dtau of an exponential is taken at its output (end of its last factor)
+            const bool stage_end = (i == M) || (chain[i].stage != it.stage);
+            if (g_tsave && stage_end) {
+                DotHArgs da{};
+                da.g = lam[cl];
+                da.x = xs[i];
+                da.udiag = udiag;
+                da.coef = coef + size_t(it.stage) * pl.NC;
+                da.coef_bstride = coef_bstride;
+                da.out = ge + size_t(it.stage) * (pl.NC + 1) + pl.NC;
+                da.out_bstride = ge_bstride;
+                da.dim = uint32_t(pl.dim);
+                da.gr = rt.garg;
+                hipLaunchKernelGGL(k_dot_hx, grid, dim3(256), 0, stream, da);
+                LAUNCH_CHECK();
+            }
+            FactorBwdArgs ba{};
+            ba.gin = lam[cl];
+            ba.xin = xs[i - 1];
+            ba.gout = lam[cl ^ 1];
+            ba.udiag = udiag;
+            ba.coef = coef + size_t(it.stage) * pl.NC;
+            ba.coef_bstride = coef_bstride;
+            ba.ge = ge + size_t(it.stage) * (pl.NC + 1);
+            ba.ge_bstride = ge_bstride;
+            ba.wtot = wtot;
+            ba.dim = uint32_t(pl.dim);
+            ba.gr = it.s.gr;
+            ba.gi = it.s.gi;
+            ba.br = it.s.br;
+            ba.bi = it.s.bi;
+            ba.g = rt.garg;
+            hipLaunchKernelGGL(k_factor_bwd_direct, grid, dim3(256), 0, stream, ba);
+            LAUNCH_CHECK();
+            cl ^= 1;
+        }
+        if (gst || have_gexp) {
+            hipLaunchKernelGGL(k_inject, grid, dim3(256), 0, stream, lam[cl], gst ? gst + size_t(k) * sv : nullptr,
+                               tape + size_t(k) * sv, obs, have_gexp ? grad_expect : nullptr, pl.n_obs, pl.T + 1, k, pl.B,
+                               uint32_t(pl.dim), 0);
+            LAUNCH_CHECK();
+        }
+    }
+    if (g_psi0) HIP_TRY(hipMemcpyAsync(g_psi0, lam[cl], pl.state_bytes, hipMemcpyDeviceToDevice, stream));
+
+    // scatter to tables / tsave
+    if (g_amp) HIP_TRY(hipMemsetAsync(g_amp, 0, size_t(pl.Bc) * pl.Ka * pl.n_samples * 16, stream));
+    if (g_det) HIP_TRY(hipMemsetAsync(g_det, 0, size_t(pl.Bc) * pl.Kd * pl.n_samples * 8, stream));
+    if (g_tsave) HIP_TRY(hipMemsetAsync(g_tsave, 0, size_t(pl.T + 1) * 8, stream));
+    if ((g_amp && pl.Ka) || (g_det && pl.Kd) || g_tsave) {
+        // extra metadata (dwdt, tinfo, tscale) lives at the start of the chain region, which is free now
+        std::vector<double> dwdt(E * 4), tscale(E);
+        std::vector<int32_t> tinfo(E * 3);
+        for (size_t e = 0; e < E; ++e) {
+            for (int q = 0; q < 4; ++q) dwdt[e * 4 + q] = pl.stages[e].dwdt[q];
+            tinfo[e * 3] = pl.stages[e].tnode;
+            tinfo[e * 3 + 1] = pl.stages[e].t_hi;
+            tinfo[e * 3 + 2] = pl.stages[e].t_lo;
+            tscale[e] = pl.stages[e].tau_scale;
+        }
+        char* m = ws + pl.off_meta2;
+        const size_t o1 = align_up(E * 4 * sizeof(double)), o2 = o1 + align_up(E * 3 * sizeof(int32_t));
+        HIP_TRY(hipMemcpyAsync(m, dwdt.data(), dwdt.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(m + o1, tinfo.data(), tinfo.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(m + o2, tscale.data(), tscale.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        ScatterArgs sa{};
+        sa.ge = ge;
+        sa.idx = reinterpret_cast<const int32_t*>(ws + pl.off_meta_idx);
+        sa.w = reinterpret_cast<const double*>(ws + pl.off_meta_w);
+        sa.dwdt = reinterpret_cast<const double*>(m);
+        sa.tinfo = reinterpret_cast<const int32_t*>(m + o1);
+        sa.tscale = reinterpret_cast<const double*>(m + o2);
+        sa.amp = static_cast<const double2*>(p->amp_tables);
+        sa.det = p->det_tables;
+        sa.g_amp = static_cast<double2*>(g_amp);
+        sa.g_det = g_det;
+        sa.g_tsave = (pl.Bc == 1 || true) ? g_tsave : nullptr;
+        sa.E = int(E);
+        sa.n_samples = pl.n_samples;
+        sa.Ka = pl.Ka;
+        sa.Kd = pl.Kd;
+        sa.NC = pl.NC;
+        sa.ga = pl.ga.n;
+        sa.gd = pl.gd.n;
+        for (int g = 0; g < pl.ga.n; ++g) sa.amem[g] = pl.ga.members[g];
+        for (int g = 0; g < pl.gd.n; ++g) sa.dmem[g] = pl.gd.members[g];
+        hipLaunchKernelGGL(k_scatter_grads, dim3((unsigned(E) + 63) / 64, pl.Bc), dim3(64), 0, stream, sa);
+        LAUNCH_CHECK();
+    }
+    if (g_u) {
+        const int npairs = pl.N * (pl.N - 1) / 2;
+        if (npairs > 0) {
+            HIP_TRY(hipMemsetAsync(g_u, 0, size_t(npairs) * 8, stream));
+            const unsigned nb = unsigned(std::min<size_t>((pl.dim + 255) / 256, 256));
+            hipLaunchKernelGGL(k_ugrad, dim3(nb, npairs), dim3(256), 0, stream, g_u, wtot, pl.N, uint32_t(pl.dim));
+            LAUNCH_CHECK();
+        }
+    }
+    return RYDIFF_OK;
+}
+
+int rydiff_apply_hamiltonian(const RydProblem* p, const double* c_amp_reim, const double* c_det, const void* x, void* y,
+                             void* workspace, size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!x || !y || !workspace) return fail(RYDIFF_EINVAL, "null buffer");
+    // build a plan without time structure: reuse build_plan with a dummy 2-point tsave if none is given
+    RydProblem q = *p;
+    double dummy_t[2] = {0.0, 1.0};
+    if (q.n_tsave < 2 || !q.tsave) {
+        q.n_tsave = 2;
+        q.tsave = dummy_t;
+    }
+    q.solver = RYDIFF_SOLVER_KRYLOV_SE;
+    Runtime rt;
+    std::string err;
+    if (!build_plan(&q, rt.pl, err)) return fail(RYDIFF_EINVAL, err);
+    Plan& pl = rt.pl;
+    fill_group_args(pl, rt.garg);
+    const size_t need = align_up(size_t(std::max(pl.NC, 1)) * sizeof(double)) + align_up(pl.dim * sizeof(double));
+    if (workspace_bytes < need) return fail(RYDIFF_EWORKSPACE, "workspace too small: need " + std::to_string(need));
+    std::vector<double> rec(std::max(pl.NC, 1), 0.0);
+    for (int g = 0; g < pl.ga.n; ++g)
+        for (int k = 0; k < pl.Ka; ++k)
+            if (pl.ga.members[g] >> k & 1ull) {
+                rec[g] += c_amp_reim[2 * k];
+                rec[pl.ga.n + g] += c_amp_reim[2 * k + 1];
+            }
+    for (int g = 0; g < pl.gd.n; ++g)
+        for (int k = 0; k < pl.Kd; ++k)
+            if (pl.gd.members[g] >> k & 1ull) rec[2 * pl.ga.n + g] += 2.0 * c_det[k];
+    char* ws = static_cast<char*>(workspace);
+    double* dcoef = reinterpret_cast<double*>(ws);
+    double* udiag = reinterpret_cast<double*>(ws + align_up(size_t(std::max(pl.NC, 1)) * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(dcoef, rec.data(), rec.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (pl.N > 1) {
+        hipLaunchKernelGGL(k_build_udiag, dim3((pl.dim + 255) / 256), dim3(256), 0, stream, udiag, p->u_pairs, pl.N, uint32_t(pl.dim));
+        LAUNCH_CHECK();
+    } else {
+        HIP_TRY(hipMemsetAsync(udiag, 0, pl.dim * sizeof(double), stream));
+    }
+    FactorArgs fa{};
+    fa.xin = static_cast<const double2*>(x);
+    fa.xout = static_cast<double2*>(y);
+    fa.udiag = udiag;
+    fa.coef = dcoef;
+    fa.coef_bstride = 0;
+    fa.dim = uint32_t(pl.dim);
+    fa.gr = 0.0;
+    fa.gi = 0.0;
+    fa.br = 1.0;
+    fa.bi = 0.0;
+    fa.g = rt.garg;
+    hipLaunchKernelGGL(k_factor_direct, dim3(unsigned((pl.dim + 255) / 256), pl.B), dim3(256), 0, stream, fa);
+    LAUNCH_CHECK();
+    return RYDIFF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,264 @@
+"""Solver seam: the MI355X-native replacement of ``pyqtorch.sesolve`` as called at
+``pulser_diff/backend.py:488-494``.
+
+The reference passes an opaque callable ``H_t`` (``pulser_diff/hamiltonian.py:526-546``) that the third-party
+solver evaluates on every sub-step, and lets torch autograd tape every one of those sub-steps.  Here the seam
+takes the STRUCTURED problem (the coefficient arrays ``build_ham_tensor`` captures, the qubits they act on, the
+pair interactions) and a ``torch.autograd.Function`` whose backward is the native adjoint sweep
+(``rydiff_backward``), so ``torch.autograd.grad(f, x, v, retain_graph=True)`` (``pulser_diff/derivative.py:40,76``)
+works unchanged on its outputs, any number of times.
+"""
+from __future__ import annotations
+
+import ctypes
+import enum
+from dataclasses import dataclass, field
+from typing import Any, Optional, Sequence
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import _native
+
+
+class SolverType(enum.Enum):
+    """Member names of ``pyqtorch.utils.SolverType`` used by the reference (``backend.py:434,483,487``)."""
+
+    DP5_SE = "dp5_se"
+    KRYLOV_SE = "krylov_se"
+    DP5_ME = "dp5_me"
+
+
+_SOLVER_CODE = {SolverType.KRYLOV_SE: _native.SOLVER_KRYLOV_SE, SolverType.DP5_SE: _native.SOLVER_DP5_SE}
+
+# options the reference forwards verbatim to pyqtorch (backend.py:435,493); the ones that steer accuracy map
+# onto the per-exponential truncation target, the others are accepted and ignored.
+_KNOWN_OPTIONS = {"atol", "rtol", "max_krylov", "exp_tolerance", "norm_tolerance", "max_steps", "tol", "use_sparse"}
+
+
+@dataclass
+class ProblemSpec:
+    """Static (non-tensor) description of one evolution problem."""
+
+    n_qubits: int
+    dt: float
+    n_samples: int
+    amp_masks: tuple[int, ...]  # bit j = term acts on qubit j
+    det_masks: tuple[int, ...]
+    solver: SolverType = SolverType.KRYLOV_SE
+    tol: float = 0.0
+    store_states: bool = True
+    options: dict = field(default_factory=dict)
+
+    def solver_code(self) -> int:
+        if self.solver not in _SOLVER_CODE:
+            raise ValueError(f"Solver {self.solver} not available.")  # backend.py:511
+        return _SOLVER_CODE[self.solver]
+
+
+def tolerance_from_options(options: dict[str, Any]) -> float:
+    unknown = set(options) - _KNOWN_OPTIONS
+    if unknown:
+        raise TypeError(f"Unknown solver option(s): {sorted(unknown)}")
+    for key in ("tol", "exp_tolerance"):
+        if key in options:
+            return float(options[key])
+    if "atol" in options or "rtol" in options:
+        # DP5-style tolerances: aim two orders below the requested local accuracy
+        return max(min(float(options.get("atol", 1e-8)), float(options.get("rtol", 1e-6))) * 1e-2, 1e-15)
+    return 0.0
+
+
+def _require_cuda(t: Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} must live on the GPU (got device {t.device}); the MI355X backend has no CPU path. "
+            "Move the inputs with .to('cuda')."
+        )
+
+
+class _Call:
+    """Keeps the ctypes structures and every buffer they point to alive for the duration of a native call."""
+
+    def __init__(self, spec: ProblemSpec, amp: Tensor, det: Tensor, u_pairs: Tensor, tsave_host: np.ndarray,
+                 batch: int, obs: Optional[Tensor]):
+        self.spec = spec
+        self.amp_masks = np.asarray(spec.amp_masks, dtype=np.uint32)
+        self.det_masks = np.asarray(spec.det_masks, dtype=np.uint32)
+        self.tsave = np.ascontiguousarray(tsave_host, dtype=np.float64)
+        self.tensors = (amp, det, u_pairs, obs)
+        p = _native.RydProblem()
+        p.n_qubits = spec.n_qubits
+        p.batch = batch
+        ka, kd = len(spec.amp_masks), len(spec.det_masks)
+        cb = 1
+        if ka:
+            cb = amp.shape[0]
+        elif kd:
+            cb = det.shape[0]
+        p.coeff_batch = cb
+        p.n_samples = spec.n_samples
+        p.dt = spec.dt
+        p.n_amp_terms = ka
+        p.n_det_terms = kd
+        p.amp_masks = self.amp_masks.ctypes.data if ka else None
+        p.det_masks = self.det_masks.ctypes.data if kd else None
+        p.amp_tables = amp.data_ptr() if ka else None
+        p.det_tables = det.data_ptr() if kd else None
+        p.u_pairs = u_pairs.data_ptr() if u_pairs.numel() else None
+        p.n_tsave = len(self.tsave)
+        p.tsave = self.tsave.ctypes.data
+        p.solver = spec.solver_code()
+        p.tol = spec.tol
+        p.n_obs = 0 if obs is None else obs.shape[0]
+        p.obs_diag = None if obs is None or obs.shape[0] == 0 else obs.data_ptr()
+        self.problem = p
+
+
+def _stream_ptr(device: torch.device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class _RydbergEvolve(torch.autograd.Function):
+    """states, expect = evolve(amp_tables, det_tables, u_pairs, tsave, psi0; obs_diag, spec)."""
+
+    @staticmethod
+    def forward(ctx, amp: Tensor, det: Tensor, u_pairs: Tensor, tsave: Tensor, psi0: Tensor,
+                obs: Optional[Tensor], spec: ProblemSpec):
+        L = _native.lib()
+        dev = psi0.device
+        for t, name in ((amp, "amp_tables"), (det, "det_tables"), (u_pairs, "u_pairs"), (psi0, "psi0")):
+            _require_cuda(t, name)
+        amp_c = amp.detach().to(torch.complex128).contiguous()
+        det_c = det.detach().to(torch.float64).contiguous()
+        u_c = u_pairs.detach().to(torch.float64).contiguous()
+        psi_c = psi0.detach().to(torch.complex128).contiguous()
+        obs_c = None if obs is None else obs.detach().to(torch.float64).contiguous()
+        ts_host = tsave.detach().to("cpu", torch.float64).numpy()
+        batch, dim = psi_c.shape
+        if dim != 2 ** spec.n_qubits:
+            raise ValueError(f"Incompatible shape of initial state.Expected {2 ** spec.n_qubits}, got {dim}.")
+        n_t = len(ts_host)
+        call = _Call(spec, amp_c, det_c, u_c, ts_host, batch, obs_c)
+        needs_grad = any(ctx.needs_input_grad[:5])
+        need_tape = bool(needs_grad and not spec.store_states)
+        with torch.cuda.device(dev):
+            stream = _stream_ptr(dev)
+            scratch = torch.empty(_native.PLAN_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
+            info = _native.RydPlanInfo()
+            # with the trajectory kept in the workspace tape, size the workspace for the backward sweep right away
+            _native.check(L.rydiff_plan(ctypes.byref(call.problem), int(need_tape), int(need_tape), _ptr(scratch),
+                                        stream, ctypes.byref(info)))
+            workspace = torch.empty(info.workspace_bytes, dtype=torch.uint8, device=dev)
+            states = (torch.empty((n_t, batch, dim), dtype=torch.complex128, device=dev) if spec.store_states
+                      else torch.empty((0, batch, dim), dtype=torch.complex128, device=dev))
+            n_obs = call.problem.n_obs
+            expect = torch.empty((n_obs, n_t, batch), dtype=torch.float64, device=dev)
+            _native.check(L.rydiff_forward(ctypes.byref(call.problem), ctypes.byref(info), _ptr(psi_c),
+                                           _ptr(states) if spec.store_states else None,
+                                           _ptr(expect) if n_obs else None, _ptr(workspace),
+                                           workspace.numel(), int(need_tape), stream))
+        ctx.spec = spec
+        ctx.info = info
+        ctx.tsave_host = ts_host
+        ctx.tsave_meta = (tsave.device, tsave.dtype)
+        ctx.in_dtypes = (amp.dtype, det.dtype, u_pairs.dtype, psi0.dtype)
+        ctx.need_tape = need_tape
+        ctx.tape_workspace = workspace if need_tape else None
+        ctx.save_for_backward(amp_c, det_c, u_c, psi_c, obs_c if obs_c is not None else torch.empty(0, device=dev),
+                              states)
+        ctx.has_obs = obs_c is not None
+        ctx.set_materialize_grads(False)
+        ctx.stats = {"degree": info.degree, "total_factors": info.total_factors, "rho": info.rho_design,
+                     "spectral": (info.spectral_lo, info.spectral_hi)}
+        spec.options["_last_stats"] = ctx.stats
+        return states, expect
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_states: Optional[Tensor], g_expect: Optional[Tensor]):
+        L = _native.lib()
+        amp_c, det_c, u_c, psi_c, obs_c, states = ctx.saved_tensors
+        spec: ProblemSpec = ctx.spec
+        dev = psi_c.device
+        batch, dim = psi_c.shape
+        obs = obs_c if ctx.has_obs else None
+        call = _Call(spec, amp_c, det_c, u_c, ctx.tsave_host, batch, obs)
+        need = ctx.needs_input_grad
+        if g_states is not None and g_states.numel() == 0:
+            g_states = None
+        if g_states is not None:
+            g_states = g_states.to(torch.complex128).contiguous()
+        if g_expect is not None:
+            g_expect = g_expect.to(torch.float64).contiguous()
+        with torch.cuda.device(dev):
+            stream = _stream_ptr(dev)
+            g_amp = torch.empty_like(amp_c) if need[0] and amp_c.numel() else None
+            g_det = torch.empty_like(det_c) if need[1] and det_c.numel() else None
+            g_u = torch.empty_like(u_c) if need[2] and u_c.numel() else None
+            g_ts = torch.empty(len(ctx.tsave_host), dtype=torch.float64, device=dev) if need[3] else None
+            g_psi = torch.empty_like(psi_c) if need[4] else None
+            info = ctx.info
+            if ctx.need_tape:
+                workspace = ctx.tape_workspace  # sized for forward + backward by the forward call
+                states_ptr = None
+            else:
+                scratch = torch.empty(_native.PLAN_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
+                info_b = _native.RydPlanInfo()
+                _native.check(L.rydiff_plan(ctypes.byref(call.problem), 0, 1, _ptr(scratch), stream,
+                                            ctypes.byref(info_b)))
+                workspace = torch.empty(info_b.workspace_bytes, dtype=torch.uint8, device=dev)
+                info = info_b
+                states_ptr = _ptr(states)
+            _native.check(L.rydiff_backward(ctypes.byref(call.problem), ctypes.byref(info), states_ptr, _ptr(g_states),
+                                            _ptr(g_expect) if (g_expect is not None and obs is not None) else None,
+                                            _ptr(g_amp), _ptr(g_det), _ptr(g_u), _ptr(g_ts), _ptr(g_psi),
+                                            _ptr(workspace), workspace.numel(), int(ctx.need_tape), stream))
+        a_dt, d_dt, u_dt, p_dt = ctx.in_dtypes
+        if g_amp is not None:
+            g_amp = g_amp.to(a_dt) if a_dt.is_complex else g_amp.real.to(a_dt)
+        if g_det is not None:
+            g_det = g_det.to(d_dt)
+        if g_u is not None:
+            g_u = g_u.to(u_dt)
+        if g_ts is not None:
+            ts_dev, ts_dt = ctx.tsave_meta
+            g_ts = g_ts.to(ts_dev, ts_dt)
+        if g_psi is not None:
+            g_psi = g_psi.to(p_dt)
+        return g_amp, g_det, g_u, g_ts, g_psi, None, None
+
+
+@dataclass
+class SolveResult:
+    """What the reference reads from pyqtorch's result object: ``.states`` iterable over time (backend.py:513-521)."""
+
+    states: Tensor  # (n_t, dim, B) view, like pyqtorch
+    expect: Tensor  # (n_obs, n_t, B) diagonal observables evaluated natively
+    stats: dict
+
+
+def evolve(amp_tables: Tensor, det_tables: Tensor, u_pairs: Tensor, tsave: Tensor, psi0: Tensor,
+           spec: ProblemSpec, obs_diag: Optional[Tensor] = None) -> tuple[Tensor, Tensor]:
+    """Low-level entry: psi0 is (B, dim); returns states (n_t, B, dim) and expect (n_obs, n_t, B)."""
+    return _RydbergEvolve.apply(amp_tables, det_tables, u_pairs, tsave, psi0, obs_diag, spec)
+
+
+def sesolve(problem, psi0: Tensor, tsave: Tensor, solver: SolverType = SolverType.DP5_SE,
+            options: Optional[dict] = None, obs_diag: Optional[Tensor] = None, store_states: bool = True) -> SolveResult:
+    """Drop-in for ``pyqtorch.sesolve(H=..., psi0, tsave, solver, options)`` at ``backend.py:488-494``.
+
+    ``problem`` is the structured Hamiltonian (``pulser_diff_amd.hamiltonian.Hamiltonian``) instead of the opaque
+    callable; ``psi0`` is ``(dim, B)`` as in the reference.
+    """
+    options = dict(options or {})
+    spec = problem.problem_spec(solver=solver, tol=tolerance_from_options(options), store_states=store_states)
+    psi_bd = psi0.reshape(psi0.shape[0], -1).transpose(0, 1)
+    states, expect = evolve(problem.amp_tables, problem.det_tables, problem.u_pairs, tsave, psi_bd, spec, obs_diag)
+    return SolveResult(states.permute(0, 2, 1) if states.numel() else states, expect,
+                       dict(spec.options.get("_last_stats", {})))

@@ -1,0 +1,61 @@
+"""Shared helpers for the parity tests: build the same problem for the CPU oracle and for the native library."""
+from __future__ import annotations
+
+import itertools
+
+import numpy as np
+import torch
+
+from oracle import restatement as R
+
+
+def random_terms(n_qubits: int, n_samples: int, dt: float, seed: int, local: bool = False, spacing: float = 8.0,
+                 amp_scale: float = 6.0, det_scale: float = 5.0, phase: bool = True) -> R.HamTerms:
+    """Random but smooth coefficient arrays (seeded) on a jittered chain register."""
+    g = torch.Generator().manual_seed(seed)
+    coords = torch.stack([torch.arange(n_qubits, dtype=torch.float64) * spacing,
+                          torch.rand(n_qubits, generator=g, dtype=torch.float64) * 2.0], dim=1)
+    t = torch.linspace(0, 1, n_samples, dtype=torch.float64)
+    amp = amp_scale * torch.sin(np.pi * t) ** 2 * (1 + 0.3 * torch.rand(1, generator=g, dtype=torch.float64))
+    ph = (0.7 * t + 0.2) if phase else torch.zeros_like(t)
+    amp_c = 0.5 * amp * torch.exp(-1j * ph.to(torch.complex128))
+    det_c = -0.5 * det_scale * (2 * t - 1 + 0.1 * torch.rand(1, generator=g, dtype=torch.float64))
+    terms = R.HamTerms(n_qubits, R.interaction_strengths(coords), amp_c, det_c, dt, n_samples,
+                       list(range(n_qubits)), list(range(n_qubits)))
+    if local:
+        q1 = [n_qubits // 2]
+        q2 = [0, n_qubits - 1] if n_qubits > 1 else [0]
+        terms.extra_amp = [(0.5 * 3.0 * torch.cos(2.0 * t).to(torch.complex128) * np.exp(-0.4j), q1)]
+        terms.extra_det = [(-0.5 * 2.0 * torch.sin(3.0 * t), q2)]
+    return terms
+
+
+def mask_of(targets) -> int:
+    m = 0
+    for q in targets:
+        m |= 1 << q
+    return m
+
+
+def to_native(terms: R.HamTerms, device, solver, tol: float = 0.0, store_states: bool = True, batch_tables: int = 1):
+    """HamTerms -> (amp_tables, det_tables, u_pairs, spec) on `device` (tables shaped [Bc, K, n])."""
+    from pulser_diff_amd.solver import ProblemSpec
+
+    amp_terms, det_terms = terms.amp_terms(), terms.det_terms()
+    n = terms.n_samples
+    amp = (torch.stack([c.to(torch.complex128) for c, _ in amp_terms]) if amp_terms
+           else torch.zeros(0, n, dtype=torch.complex128))
+    det = (torch.stack([c.to(torch.float64) for c, _ in det_terms]) if det_terms
+           else torch.zeros(0, n, dtype=torch.float64))
+    amp = amp.unsqueeze(0).repeat(batch_tables, 1, 1).to(device)
+    det = det.unsqueeze(0).repeat(batch_tables, 1, 1).to(device)
+    spec = ProblemSpec(terms.n_qubits, terms.dt, n, tuple(mask_of(tg) for _, tg in amp_terms),
+                       tuple(mask_of(tg) for _, tg in det_terms), solver=solver, tol=tol, store_states=store_states)
+    return amp, det, terms.u_pairs.detach().to(device), spec
+
+
+def rel_err(a, b) -> float:
+    a = np.asarray(a)
+    b = np.asarray(b)
+    den = max(float(np.abs(b).max()), 1e-300)
+    return float(np.abs(a - b).max() / den)

@@ -1,0 +1,176 @@
+"""GPU parity: native library (through the C ABI) vs the CPU oracle on identical seeded inputs.
+
+Tolerances (north_star): <= 1e-8 relative error on final |psi> and on gradients; the Krylov discrete map
+(right-endpoint H freezing) is the primary parity definition."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import restatement as R
+from tests.helpers import random_terms, rel_err, to_native
+
+pytestmark = pytest.mark.gpu
+
+STATE_RTOL = 1e-9
+GRAD_RTOL = 1e-8
+
+
+def _native_run(terms, tsave, psi0_bd, device, obs=None, **kw):
+    from pulser_diff_amd.solver import SolverType, evolve
+
+    amp, det, u, spec = to_native(terms, device, SolverType.KRYLOV_SE, **kw)
+    states, expect = evolve(amp, det, u, tsave, psi0_bd.to(device), spec,
+                            None if obs is None else obs.to(device))
+    torch.cuda.synchronize()
+    return states, expect, spec
+
+
+@pytest.mark.parametrize("n_qubits,local", [(1, False), (2, False), (3, True), (5, True), (8, False), (9, True)])
+def test_states_and_expectation_match_oracle(cuda_device, n_qubits, local):
+    n_samples, dt = 41, 0.004
+    terms = random_terms(n_qubits, n_samples, dt, seed=10 + n_qubits, local=local)
+    tsave = torch.linspace(0, dt * (n_samples - 1), 25, dtype=torch.float64)
+    psi0 = R.all_ground_state(n_qubits)
+    ref = R.krylov_map_dense(terms, psi0, tsave)  # (n_t, dim, 1)
+    zdiag = R.total_magnetization_diag(n_qubits)
+    obs = torch.stack([zdiag, R.occupation_table(n_qubits)[0]])
+    states, expect, spec = _native_run(terms, tsave, psi0.T.contiguous(), cuda_device, obs=obs)
+    got = states.cpu().permute(0, 2, 1)
+    assert rel_err(got.numpy(), ref.numpy()) < STATE_RTOL
+    ref_e = torch.stack([(ref.abs() ** 2 * o[None, :, None]).sum(1) for o in obs])  # (n_obs, n_t, B)
+    assert np.abs(expect.cpu().numpy() - ref_e.numpy()).max() < 1e-9
+    # norm conservation (size-independent property)
+    nrm = (got.abs() ** 2).sum(1)
+    assert np.abs(nrm.numpy() - 1).max() < 1e-11
+
+
+def test_irregular_time_grid_like_sampling_rate_below_one(cuda_device):
+    """tsave with irregular 10/11-ns spacing and clamped interpolation indices (hamiltonian.py:83-91,532-533)."""
+    seq = R.concat_pulses([(R.blackman_waveform(400, np.pi), R.ramp_waveform(400, -5.0, 0.0), 0.0),
+                           (R.constant_waveform(300, 5.0), R.constant_waveform(300, 1.0), 0.3)])
+    coords = torch.tensor([[0, 0], [0, 8], [8, 0], [8, 8]], dtype=torch.float64)
+    terms = R.build_terms(seq, coords, 0.1)
+    tsave = R.evaluation_times(seq.tot_duration, 0.1)
+    psi0 = R.all_ground_state(4)
+    ref = R.krylov_map_dense(terms, psi0, tsave)
+    states, _, _ = _native_run(terms, tsave, psi0.T.contiguous(), cuda_device)
+    assert rel_err(states.cpu().permute(0, 2, 1).numpy(), ref.numpy()) < STATE_RTOL
+
+
+def test_batched_initial_states_shared_tables(cuda_device):
+    """psi0 of shape (dim, B) as in the gate-optimisation notebook (initial_state=torch.eye(2**n))."""
+    n = 3
+    terms = random_terms(n, 31, 0.005, seed=3, local=True)
+    tsave = torch.linspace(0, 0.15, 16, dtype=torch.float64)
+    psi0 = torch.eye(2**n, dtype=torch.complex128)
+    ref = R.krylov_map_dense(terms, psi0, tsave)  # (n_t, dim, B)
+    states, _, _ = _native_run(terms, tsave, psi0.T.contiguous(), cuda_device)
+    assert rel_err(states.cpu().permute(0, 2, 1).numpy(), ref.numpy()) < STATE_RTOL
+
+
+def _loss_from(states_tdb, expect, weights, probe):
+    """A generic real loss touching every saved state, the expectation values and the final state."""
+    final = states_tdb[-1]
+    return ((weights[:, None] * expect[0]).sum() + (probe.conj()[:, None] * final).sum().real
+            + 0.3 * (states_tdb[len(states_tdb) // 2].abs() ** 2 * torch.arange(final.shape[0], device=final.device,
+                                                                               dtype=torch.float64)[:, None]).sum() / final.shape[0])
+
+
+@pytest.mark.parametrize("n_qubits,local,batch", [(2, False, 1), (4, True, 1), (6, True, 1), (3, True, 2)])
+def test_gradients_match_oracle_autograd(cuda_device, n_qubits, local, batch):
+    """Adjoint sweep vs torch autograd through the oracle's dense matrix_exp map: gradients w.r.t. the coefficient
+    tables, pair interactions, evaluation times and initial state."""
+    from pulser_diff_amd.solver import SolverType, evolve
+
+    n_samples, dt = 33, 0.004
+    terms = random_terms(n_qubits, n_samples, dt, seed=100 + n_qubits, local=local)
+    tsave0 = torch.linspace(0, dt * (n_samples - 1), 12, dtype=torch.float64)
+    tsave0 = tsave0 + torch.cat([torch.zeros(1), 0.0007 * torch.rand(10, generator=torch.Generator().manual_seed(1), dtype=torch.float64), torch.zeros(1)])
+    gen = torch.Generator().manual_seed(7)
+    dim = 2**n_qubits
+    psi0 = torch.randn(dim, batch, generator=gen, dtype=torch.complex128)
+    psi0 = psi0 / psi0.norm(dim=0, keepdim=True)
+    weights = torch.randn(len(tsave0), generator=gen, dtype=torch.float64)
+    probe = torch.randn(dim, generator=gen, dtype=torch.complex128)
+    zdiag = R.total_magnetization_diag(n_qubits)
+
+    # ---- oracle: leaves = every coefficient array, u_pairs, tsave, psi0
+    leaves = {}
+    o_terms = R.HamTerms(n_qubits, terms.u_pairs.clone().requires_grad_(True),
+                         terms.amp_coeff.clone().requires_grad_(True), terms.det_coeff.clone().requires_grad_(True),
+                         dt, n_samples, terms.amp_targets, terms.det_targets)
+    o_terms.extra_amp = [(c.clone().requires_grad_(True), tg) for c, tg in terms.extra_amp]
+    o_terms.extra_det = [(c.clone().requires_grad_(True), tg) for c, tg in terms.extra_det]
+    o_ts = tsave0.clone().requires_grad_(True)
+    o_psi = psi0.clone().requires_grad_(True)
+    o_states = R.krylov_map_dense(o_terms, o_psi, o_ts)  # (n_t, dim, B)
+    o_exp = (o_states.abs() ** 2 * zdiag[None, :, None]).sum(1)[None]  # (1, n_t, B)
+    o_loss = _loss_from(o_states, o_exp, weights, probe)
+    o_loss.backward()
+    o_amp = torch.stack([c.grad for c, _ in o_terms.amp_terms()])
+    o_det = torch.stack([c.grad for c, _ in o_terms.det_terms()])
+
+    # ---- native
+    amp, det, u, spec = to_native(terms, cuda_device, SolverType.KRYLOV_SE)
+    amp.requires_grad_(True)
+    det.requires_grad_(True)
+    u.requires_grad_(True)
+    ts = tsave0.clone().requires_grad_(True)
+    psi_bd = psi0.T.contiguous().to(cuda_device).requires_grad_(True)
+    states, expect = evolve(amp, det, u, ts, psi_bd, spec, zdiag[None].to(cuda_device))
+    loss = _loss_from(states.permute(0, 2, 1), expect, weights.to(cuda_device), probe.to(cuda_device))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - o_loss.item()) < 1e-9 * max(1.0, abs(o_loss.item()))
+    assert rel_err(amp.grad[0].cpu().numpy(), o_amp.numpy()) < GRAD_RTOL
+    assert rel_err(det.grad[0].cpu().numpy(), o_det.numpy()) < GRAD_RTOL
+    if n_qubits > 1:
+        assert rel_err(u.grad.cpu().numpy(), o_terms.u_pairs.grad.numpy()) < GRAD_RTOL
+    assert rel_err(ts.grad.numpy(), o_ts.grad.numpy()) < GRAD_RTOL
+    assert rel_err(psi_bd.grad.T.cpu().numpy(), o_psi.grad.numpy()) < GRAD_RTOL
+
+
+def test_per_trajectory_tables_and_tape_mode(cuda_device):
+    """coeff_batch == batch (independent pulse-parameter sets, BASELINE config 4) with the trajectory kept in the
+    workspace tape (store_states=False): per-trajectory gradients equal the single-trajectory ones."""
+    from pulser_diff_amd.solver import SolverType, evolve
+
+    n = 4
+    zdiag = R.total_magnetization_diag(n).to(cuda_device)
+    tsave = torch.linspace(0, 0.12, 13, dtype=torch.float64)
+    psi0 = R.all_ground_state(n).T.contiguous().to(cuda_device)
+    singles = []
+    tabs = []
+    for b in range(3):
+        terms = random_terms(n, 31, 0.004, seed=40 + b, local=False)
+        amp, det, u, spec = to_native(terms, cuda_device, SolverType.KRYLOV_SE)
+        u = tabs[0][2] if tabs else u  # one register for the whole batch: only the pulse parameters differ
+        amp.requires_grad_(True)
+        det.requires_grad_(True)
+        _, e = evolve(amp, det, u, tsave, psi0, spec, zdiag[None])
+        e[0, -1, 0].backward()
+        singles.append((e[0, :, 0].detach().clone(), amp.grad.clone(), det.grad.clone()))
+        tabs.append((amp.detach(), det.detach(), u, spec))
+    amp_b = torch.cat([t[0] for t in tabs]).requires_grad_(True)
+    det_b = torch.cat([t[1] for t in tabs]).requires_grad_(True)
+    spec = tabs[0][3]
+    spec.store_states = False
+    states, e = evolve(amp_b, det_b, tabs[0][2], tsave, psi0.repeat(3, 1), spec, zdiag[None])
+    assert states.numel() == 0
+    e[0, -1, :].sum().backward()
+    torch.cuda.synchronize()
+    for b in range(3):
+        assert np.abs((e[0, :, b].detach() - singles[b][0]).cpu().numpy()).max() < 1e-11
+        assert rel_err(amp_b.grad[b].cpu().numpy(), singles[b][1][0].cpu().numpy()) < 1e-9
+        assert rel_err(det_b.grad[b].cpu().numpy(), singles[b][2][0].cpu().numpy()) < 1e-9
+
+
+def test_twelve_qubit_chain_against_matrix_free_oracle(cuda_device):
+    """BASELINE config 2 shape (12-qubit chain) at a size the oracle finishes in seconds."""
+    n = 12
+    terms = random_terms(n, 21, 0.001, seed=5, local=False, phase=False)
+    tsave = torch.linspace(0, 0.02, 21, dtype=torch.float64)
+    psi0 = R.all_ground_state(n)
+    ref = R.krylov_map_matrix_free(terms, psi0.numpy(), tsave.numpy(), save_all=False, tol=1e-14)
+    states, _, spec = _native_run(terms, tsave, psi0.T.contiguous(), cuda_device)
+    assert rel_err(states[-1].cpu().numpy().T, ref[-1]) < STATE_RTOL
