@@ -539,3 +539,110 @@ def continuous_solution(terms: HamTerms, psi0: np.ndarray, tsave: np.ndarray,
                     np.asarray(psi0, dtype=np.complex128).reshape(-1), method="DOP853", t_eval=np.asarray(tsave),
                     rtol=rtol, atol=atol, max_step=float(terms.dt))
     return sol.y.T.reshape((len(tsave),) + shape)
+
+
+# --------------------------------------------------------------------------------------
+# CPU baseline workload: the reference's own per-step pattern, timed by bench.py's cpu_baseline leg.
+# --------------------------------------------------------------------------------------
+def krylov_step_sparse_torch(ham: Tensor, psi: Tensor, tau, max_krylov: int = 80, tol: float = 1e-10) -> Tensor:
+    """exp(-i*tau*H) psi with H a torch sparse COO matrix, by Lanczos in torch (autograd-capable).
+    pyqtorch KRYLOV_SE restated: builds the Krylov basis with sparse mat-vecs, exponentiates the small
+    tridiagonal matrix, stops on the residual estimate."""
+    nrm = torch.linalg.vector_norm(psi)
+    basis = [psi / nrm]
+    alphas, betas = [], []
+    coeffs = None
+    for j in range(max_krylov):
+        w = torch.sparse.mm(ham, basis[j].unsqueeze(1)).squeeze(1)
+        a = torch.vdot(basis[j], w).real
+        w = w - a * basis[j]
+        if j > 0:
+            w = w - betas[-1] * basis[j - 1]
+        alphas.append(a)
+        beta = torch.linalg.vector_norm(w)
+        m = len(alphas)
+        tri = torch.zeros(m, m, dtype=CDTYPE)
+        idx = torch.arange(m)
+        tri[idx, idx] = torch.stack(alphas).to(CDTYPE)
+        if m > 1:
+            b = torch.stack(betas).to(CDTYPE)
+            tri[idx[:-1], idx[1:]] = b
+            tri[idx[1:], idx[:-1]] = b
+        coeffs = torch.linalg.matrix_exp(-1j * tau * tri)[:, 0]
+        if float(beta) * abs(complex(coeffs[-1])) * abs(float(tau)) < tol or float(beta) < 1e-14:
+            break
+        betas.append(beta)
+        basis.append(w / beta)
+    out = sum(c * b for c, b in zip(coeffs, basis))
+    return nrm * out
+
+
+def reference_pattern_krylov(terms: HamTerms, psi0: Tensor, tsave: Tensor, H_t=None):
+    """The reference's CPU path for KRYLOV_SE, step by step: re-assemble sparse H(t) (hamiltonian.py:526-546),
+    then a Krylov exponential; everything on the autograd tape like the reference (derivative.py:40,76).
+    psi0: (dim,) complex.  Returns (final state, number of sparse mat-vecs)."""
+    if H_t is None:
+        H_t = reference_style_H_t(terms)
+    psi = psi0
+    for k in range(len(tsave) - 1):
+        ham = H_t(tsave[k + 1]).coalesce()
+        psi = krylov_step_sparse_torch(ham, psi, tsave[k + 1] - tsave[k])
+    return psi
+
+
+def fast_reference_operators(terms: HamTerms):
+    """The same sparse COO operators as reference_style_operators, assembled by index arithmetic instead of
+    N-fold Kronecker products (setup only — keeps the bench's CPU leg short; equality is asserted in tests)."""
+    n = terms.n_qubits
+    dim = 2**n
+    x = torch.arange(dim)
+    occ = [(1 - ((x >> (n - 1 - j)) & 1)).to(RDTYPE) for j in range(n)]
+    diag = torch.zeros(dim, dtype=RDTYPE)
+    for k, (i, j) in enumerate(itertools.combinations(range(n), 2)):
+        diag = diag + 0.5 * terms.u_pairs[k].detach() * occ[i] * occ[j]
+    nz = torch.nonzero(diag, as_tuple=False).squeeze(1)
+    if nz.numel() == 0:
+        nz = torch.zeros(1, dtype=torch.long)
+    int_mat = torch.sparse_coo_tensor(torch.stack([nz, nz]), diag[nz].to(CDTYPE), (dim, dim)).coalesce()
+
+    def flips(targets):
+        rows, cols = [], []
+        for q in targets:
+            m = 1 << (n - 1 - q)
+            r = x[(x & m) != 0]
+            rows.append(r)
+            cols.append(r ^ m)
+        return torch.sparse_coo_tensor(torch.stack([torch.cat(rows), torch.cat(cols)]),
+                                       torch.ones(sum(len(r) for r in rows), dtype=CDTYPE), (dim, dim)).coalesce()
+
+    def occs(targets):
+        d = sum(occ[q] for q in targets)
+        nzd = torch.nonzero(d, as_tuple=False).squeeze(1)
+        return torch.sparse_coo_tensor(torch.stack([nzd, nzd]), d[nzd].to(CDTYPE), (dim, dim)).coalesce()
+
+    amp_mats = [(flips(tg), c) for c, tg in terms.amp_terms()]
+    det_mats = [(occs(tg), (1.0 + 0.0j) * c) for c, tg in terms.det_terms()]
+    return int_mat, amp_mats, det_mats
+
+
+def reference_style_H_t_fast(terms: HamTerms) -> Callable[[float], Tensor]:
+    """reference_style_H_t with the fast operator setup; the per-call re-assembly is identical."""
+    int_mat, amp_mats, det_mats = fast_reference_operators(terms)
+    dt, n_samples = terms.dt, terms.n_samples
+
+    def H_t(t):
+        if not isinstance(t, Tensor):
+            t = torch.tensor(t, dtype=RDTYPE)
+        i1, i2 = interp_indices(float(t), dt, n_samples)
+        ham = 2 * int_mat
+        for det_mat, det_val in det_mats:
+            det = det_val[i1] + (det_val[i2] - det_val[i1]) * (t - i1 * dt) / dt
+            ham_mat = det_mat * det
+            ham = ham + ham_mat + ham_mat.adjoint()
+        for amp_mat, amp_val in amp_mats:
+            amp = amp_val[i1] + (amp_val[i2] - amp_val[i1]) * (t - i1 * dt) / dt
+            ham_mat = amp_mat * amp
+            ham = ham + ham_mat + ham_mat.adjoint()
+        return ham
+
+    return H_t
