@@ -41,28 +41,33 @@ RDTYPE = torch.float64
 # --------------------------------------------------------------------------------------
 # Waveform samplers (pulser.waveforms restated; pinned by KA-1..KA-5)
 # --------------------------------------------------------------------------------------
+def _rd(v) -> Tensor:
+    """Python numbers stay float64; torch tensors (e.g. the notebook's float32 leaves) are up-cast."""
+    return v.to(RDTYPE) if isinstance(v, Tensor) else torch.as_tensor(v, dtype=RDTYPE)
+
+
 def blackman_waveform(duration: int, area) -> Tensor:
     """pulser BlackmanWaveform: clip(np.blackman(d), 0) * area / sum / 1e-3 (rad/us)."""
     win = torch.as_tensor(np.clip(np.blackman(int(duration)), 0.0, np.inf), dtype=RDTYPE)
-    area = torch.as_tensor(area).to(RDTYPE)
+    area = _rd(area)
     return win * (area / (win.sum() * 1e-3))
 
 
 def ramp_waveform(duration: int, start, stop) -> Tensor:
     """pulser RampWaveform: start + (stop-start) * k/(d-1)."""
-    start = torch.as_tensor(start).to(RDTYPE)
-    stop = torch.as_tensor(stop).to(RDTYPE)
+    start = _rd(start)
+    stop = _rd(stop)
     k = torch.arange(int(duration), dtype=RDTYPE)
     return start + (stop - start) * k / (int(duration) - 1)
 
 
 def constant_waveform(duration: int, value) -> Tensor:
-    value = torch.as_tensor(value).to(RDTYPE)
+    value = _rd(value)
     return value * torch.ones(int(duration), dtype=RDTYPE)
 
 
 def custom_waveform(samples) -> Tensor:
-    return torch.as_tensor(samples).to(RDTYPE)
+    return _rd(samples)
 
 
 @dataclass
@@ -86,9 +91,9 @@ def concat_pulses(pulses: Sequence[tuple[Tensor, Tensor, Tensor | float]]) -> Sa
     """Concatenate (amp, det, phase) pulses on one channel and pad one trailing sample."""
     amps, dets, phases = [], [], []
     for amp, det, phase in pulses:
-        amp = torch.as_tensor(amp).to(RDTYPE)
-        det = torch.as_tensor(det).to(RDTYPE)
-        ph = torch.as_tensor(phase).to(RDTYPE)
+        amp = _rd(amp)
+        det = _rd(det)
+        ph = _rd(phase)
         if ph.ndim == 0 or ph.numel() == 1:
             ph = ph.reshape(()) * torch.ones_like(amp)
         amps.append(amp)

@@ -1,0 +1,303 @@
+"""``TorchEmulator``: same constructor, properties and ``run`` signature as ``pulser_diff/backend.py:35-711``, with the
+solver seam (``backend.py:488-494``) served by the MI355X-native library instead of ``pyqtorch.sesolve``.
+
+What changes for a user switching over:
+  * tensors handed to / returned by the solver live on the GPU (``compute_device``, default ``"cuda"``); leaf
+    parameters may stay on the CPU — the (tiny) coefficient tables are moved, gradients flow back through the move;
+  * ``run(..., observables=[DiagonalObservable(...)], store_states=False)`` evaluates diagonal observables natively
+    and keeps the trajectory inside the solver workspace — the only way to run a 20-qubit sequence, where a dense
+    observable (2^40 entries) or an autograd tape through every sub-step cannot exist;
+  * noise (``SimConfig(noise=...)``), the digital / XY bases and SLM masks raise ``NotImplementedError``.
+"""
+from __future__ import annotations
+
+from bisect import bisect_left
+from dataclasses import replace
+from typing import Any, Optional, Union
+
+import torch
+from torch import Tensor
+
+from . import pulses
+from .hamiltonian import Hamiltonian
+from .simconfig import SimConfig
+from .simresults import CoherentResults, SimulationResults
+from .solver import SolverType, sesolve
+from .utils import DiagonalObservable
+
+
+class TorchEmulator:
+    r"""Emulator of a pulse sequence using the MI355X-native solver.
+
+    Args:
+        sampled_seq: A pulse sequence samples used in the emulation.
+        register: The register associating coordinates to the qubits targeted by the pulses within the samples.
+        device: The device specifications used in the emulation.
+        sampling_rate: The fraction of samples that we wish to extract from the samples to simulate.
+        config: Configuration to be used for this simulation.
+        evaluation_times: "Full", "Minimal", an array of times in us, or a float fraction (``backend.py:47-58``).
+        compute_device: torch device of the native solver (extension; default "cuda").
+    """
+
+    def __init__(self, sampled_seq, register, device, sampling_rate: float = 1.0, config: Optional[SimConfig] = None,
+                 evaluation_times: Union[float, str, Any] = "Full", compute_device: Union[str, torch.device] = "cuda") -> None:
+        if not isinstance(sampled_seq, pulses.SequenceSamples):
+            raise TypeError("The provided sequence has to be a valid " "SequenceSamples instance.")
+        if sampled_seq.max_duration == 0:
+            raise ValueError("SequenceSamples is empty.")
+        device.validate_register(register)
+        self._register = register
+        if sampled_seq._slm_mask.end > 0 and not device.supports_slm_mask:
+            raise ValueError("Samples use SLM mask but device does not have one.")
+        if not sampled_seq.used_bases <= set(device.supported_bases):
+            raise ValueError("Bases used in samples should be supported by device.")
+        if not sampled_seq._slm_mask.targets <= set(register.qubit_ids):
+            raise ValueError("The ids of qubits targeted in SLM mask should be defined in register.")
+        samples_list = []
+        for ch, ch_samples in sampled_seq.channel_samples.items():
+            if sampled_seq._ch_objs[ch].addressing == "Local":
+                if not set().union(*(slot.targets for slot in ch_samples.slots)) <= set(register.qubit_ids):
+                    raise ValueError("The ids of qubits targeted in Local channels" " should be defined in register.")
+                samples_list.append(ch_samples)
+            else:
+                # Replace targets of Global channels by qubits of register (backend.py:102-112)
+                samples_list.append(replace(ch_samples, slots=[replace(slot, targets=frozenset(register.qubit_ids))
+                                                               for slot in ch_samples.slots]))
+        _sampled_seq = replace(sampled_seq, samples_list=samples_list)
+        self._tot_duration = _sampled_seq.max_duration
+        self.samples_obj = _sampled_seq.extend_duration(self._tot_duration + 1)  # backend.py:115
+
+        if not (0 < sampling_rate <= 1.0):
+            raise ValueError(
+                "The sampling rate (`sampling_rate` = "
+                f"{sampling_rate}) must be greater than 0 and "
+                "less than or equal to 1."
+            )
+        if int(self._tot_duration * sampling_rate) < 4:
+            raise ValueError("`sampling_rate` is too small, less than 4 data points.")
+        self._compute_device = torch.device(compute_device)
+        noise_model = config.to_noise_model() if config else SimConfig().to_noise_model()
+        self._config = config if config else SimConfig()
+        self._hamiltonian = Hamiltonian(self.samples_obj, self._register.qubits, device, sampling_rate, noise_model,
+                                        compute_device=self._compute_device)
+        self._eval_times_array: Tensor
+        self.set_evaluation_times(evaluation_times)
+        self._meas_basis = self.samples_obj._measurement or self._hamiltonian.basis_name
+        self.set_initial_state("all-ground")
+        self.dist_dict: dict[str, Tensor] = {}
+
+    # ---- properties (backend.py:153-181) ----------------------------------------------------------------
+    @property
+    def sampling_times(self) -> Tensor:
+        return self._hamiltonian.sampling_times
+
+    @property
+    def _sampling_rate(self) -> float:
+        return self._hamiltonian._sampling_rate
+
+    @property
+    def dim(self) -> int:
+        return self._hamiltonian.dim
+
+    @property
+    def basis_name(self) -> str:
+        return self._hamiltonian.basis_name
+
+    @property
+    def basis(self) -> dict:
+        return self._hamiltonian.basis
+
+    @property
+    def config(self) -> SimConfig:
+        return self._config
+
+    def set_config(self, cfg: SimConfig) -> None:
+        """backend.py:183-198."""
+        if not isinstance(cfg, SimConfig):
+            raise ValueError(f"Object {cfg} is not a valid `SimConfig`.")
+        not_supported = set(cfg.noise) - cfg.supported_noises[self._hamiltonian._interaction]
+        if not_supported:
+            raise NotImplementedError(
+                f"Interaction mode '{self._hamiltonian._interaction}' does not"
+                " support simulation of noise types:"
+                f"{', '.join(not_supported)}."
+            )
+        self._hamiltonian.set_config(cfg.to_noise_model())
+        self._config = cfg
+
+    def add_config(self, config: SimConfig) -> None:
+        """backend.py:200-238 (only noiseless configurations can be merged on this backend)."""
+        if not isinstance(config, SimConfig):
+            raise ValueError(f"Object {config} is not a valid `SimConfig`")
+        self.set_config(replace(self._config, noise=tuple(set(self._config.noise) | set(config.noise))))
+
+    def show_config(self, solver_options: bool = False) -> None:
+        print(self.config.__str__(solver_options))
+
+    def reset_config(self) -> None:
+        self.set_config(SimConfig())
+
+    @property
+    def initial_state(self) -> Tensor:
+        return self._initial_state
+
+    def set_initial_state(self, state: Union[str, Tensor]) -> None:
+        """backend.py:253-280: "all-ground" or a (dim[, B]) tensor."""
+        n = self._hamiltonian._size
+        if isinstance(state, str) and state == "all-ground":
+            psi = torch.zeros(2**n, 1, dtype=torch.complex128)
+            psi[-1, 0] = 1.0  # kron of N |g> kets = last basis vector (r=0, g=1)
+            self._initial_state = psi
+        else:
+            shape = state.shape[0]
+            legal_shape = self._hamiltonian.dim**n
+            if shape != legal_shape:
+                raise ValueError("Incompatible shape of initial state." + f"Expected {legal_shape}, got {shape}.")
+            self._initial_state = state.to(torch.complex128)
+
+    @property
+    def evaluation_times(self) -> Tensor:
+        return self._eval_times_array
+
+    @property
+    def qq_distances(self) -> dict:
+        return self.dist_dict
+
+    @property
+    def endtimes(self) -> list:
+        """backend.py:291-310."""
+        end_ts = [0]
+        remaining_indices = torch.linspace(0, self._tot_duration, int(self._sampling_rate * (self._tot_duration + 1)),
+                                           dtype=torch.int)
+        for samples in self.samples_obj.samples_list:
+            end_ts += [bisect_left(remaining_indices.numpy(), sl.tf) - 1 for sl in samples.slots]
+            end_ts += [bisect_left(remaining_indices.numpy(), sl.tf) for sl in samples.slots]
+        return sorted(end_ts)
+
+    def set_evaluation_times(self, value) -> None:
+        """backend.py:312-375."""
+        st = self._hamiltonian.sampling_times
+        if isinstance(value, str):
+            if value == "Full":
+                eval_times = torch.clone(st)
+            elif value == "Minimal":
+                eval_times = torch.tensor([], dtype=st.dtype)
+            else:
+                raise ValueError(
+                    "Wrong evaluation time label. It should "
+                    "be `Full`, `Minimal`, an array of times or" + " a float between 0 and 1."
+                )
+        elif isinstance(value, float):
+            if value > 1 or value <= 0:
+                raise ValueError("evaluation_times float must be between 0 and 1.")
+            indices = torch.linspace(0, len(st) - 1, int(value * len(st)), dtype=torch.int)
+            eval_times = st[indices.long()]
+        elif isinstance(value, (list, tuple, Tensor)):
+            if torch.max(torch.as_tensor(value)) > self._tot_duration / 1000:
+                raise ValueError("Provided evaluation-time list extends " "further than sequence duration.")
+            if torch.min(torch.as_tensor(value)) < 0:
+                raise ValueError("Provided evaluation-time list contains " "negative values.")
+            eval_times = torch.as_tensor(value, dtype=torch.float64)
+        else:
+            raise ValueError(
+                "Wrong evaluation time label. It should "
+                "be `Full`, `Minimal`, an array of times or a " + "float between 0 and 1."
+            )
+        self._eval_times_array = (
+            torch.cat([eval_times, torch.tensor([0.0, self._tot_duration / 1000], dtype=eval_times.dtype)])
+            .unique()
+            .requires_grad_(False)
+        )
+        self._eval_times_instruction = value
+
+    def build_operator(self, operations) -> Tensor:
+        return self._hamiltonian.build_operator(operations)
+
+    def get_hamiltonian(self, time: float) -> Tensor:
+        """backend.py:401-427 (explicit matrix; small registers)."""
+        if time > self._tot_duration:
+            raise ValueError(
+                f"Provided time (`time` = {time}) must be "
+                "less than or equal to the sequence duration "
+                f"({self._tot_duration})."
+            )
+        if time < 0:
+            raise ValueError(f"Provided time (`time` = {time}) must be " "greater than or equal to 0.")
+        return self._hamiltonian._hamiltonian(time / 1000)
+
+    # ---- run (backend.py:430-611) -------------------------------------------------------------------------
+    def run(self, time_grad: bool = False, dist_grad: bool = False, solver: SolverType = SolverType.DP5_SE,
+            observables: Optional[list] = None, store_states: bool = True, **options: Any) -> SimulationResults:
+        """Simulates the sequence with the native solver and returns ``CoherentResults``.
+
+        ``observables`` (extension): diagonal observables (``DiagonalObservable`` or dense diagonal tensors) to be
+        evaluated natively at every evaluation time; ``store_states=False`` keeps the trajectory out of the results.
+        """
+        if time_grad:
+            self._eval_times_array.requires_grad_(True)  # backend.py:453-455
+        if dist_grad:
+            for k, v in self._hamiltonian._dist_dict.items():  # backend.py:456-460
+                if v.requires_grad:
+                    v.retain_grad()
+                else:
+                    v.requires_grad_(True)  # constant register: make r_ij a leaf and reconnect U_ij to it
+                self.dist_dict[k] = v
+            self._hamiltonian._rebuild_u_pairs()
+        if self.config.noise:
+            raise NotImplementedError("Noisy simulations are not implemented in the MI355X-native backend.")
+        if solver == SolverType.DP5_ME:
+            raise NotImplementedError("The master-equation solver DP5_ME is not part of the native hot path.")
+        if solver not in (SolverType.DP5_SE, SolverType.KRYLOV_SE):
+            raise ValueError(f"Solver {solver} not available.")
+
+        dev = self._compute_device
+        ham = self._hamiltonian
+        obs_tensors, obs_objs = [], []
+        for obs in observables or []:
+            if isinstance(obs, DiagonalObservable):
+                diag = obs.diag
+            elif isinstance(obs, Tensor) and obs.ndim == 2:
+                dense = obs.to_dense() if obs.is_sparse else obs
+                if not torch.equal(torch.diag(torch.diagonal(dense)), dense):
+                    raise ValueError("Only diagonal observables can be evaluated natively; use results.expect on the states.")
+                diag = torch.diagonal(dense).real
+            else:
+                raise TypeError("observables must be DiagonalObservable objects or diagonal (dim, dim) tensors")
+            obs_tensors.append(diag.to(dev, torch.float64))
+            obs_objs.append(obs)
+        obs_diag = torch.stack(obs_tensors) if obs_tensors else None
+
+        psi0 = self.initial_state
+        if psi0.ndim == 1:
+            psi0 = psi0.unsqueeze(1)
+        result = sesolve(ham, psi0.to(dev), self._eval_times_array, solver=solver, options=options, obs_diag=obs_diag,
+                         store_states=store_states)
+        states_tbd = result.states.permute(0, 2, 1) if result.states.numel() else result.states
+        return CoherentResults(states_tbd, ham._size, ham.basis_name, self._eval_times_array, self._meas_basis, None,
+                               atom_order=tuple(ham._qdict), native_expect=result.expect if obs_diag is not None else None,
+                               native_observables=obs_objs, stats=result.stats)
+
+    @classmethod
+    def from_sequence(cls, sequence, sampling_rate: float = 1.0, config: Optional[SimConfig] = None,
+                      evaluation_times: Union[float, str, Any] = "Full", with_modulation: bool = False,
+                      compute_device: Union[str, torch.device] = "cuda") -> "TorchEmulator":
+        r"""backend.py:651-711."""
+        if not isinstance(sequence, pulses.Sequence):
+            raise TypeError("The provided sequence has to be a valid pulser.Sequence instance.")
+        if sequence.is_parametrized() or sequence.is_register_mappable():
+            raise ValueError(
+                "The provided sequence needs to be built to be simulated. Call"
+                " `Sequence.build()` with the necessary parameters."
+            )
+        if not sequence._schedule:
+            raise ValueError("The provided sequence has no declared channels.")
+        if all(sequence.get_duration(ch) == 0 for ch in sequence.declared_channels):
+            raise ValueError("No instructions given for the channels in the sequence.")
+        if with_modulation and sequence._slm_mask_targets:
+            raise NotImplementedError(
+                "Simulation of sequences combining an SLM mask and output " "modulation is not supported."
+            )
+        return cls(
+            pulses.sample(sequence, modulation=with_modulation,
+                          extended_duration=sequence.get_duration(include_fall_time=with_modulation)),
+            sequence.register, sequence.device, sampling_rate, config, evaluation_times, compute_device=compute_device)

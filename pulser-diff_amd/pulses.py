@@ -1,0 +1,377 @@
+"""Minimal, differentiable stand-ins for the Pulser objects the hot path consumes.
+
+The reference sits on ``pulser-core`` (``Sequence``, ``Register``, waveforms, ``sampler.sample`` ->
+``SequenceSamples``; imported at ``pulser_diff/backend.py:10-19`` and ``pulser_diff/hamiltonian.py:11-16``).
+Pulser is not part of this repository's scope: these classes provide just the surface
+``TorchEmulator`` needs — per-ns amplitude / detuning / phase samples per channel, target slots, register
+coordinates and the device's C6 — as torch tensors so gradients flow to the user's leaf parameters exactly as
+they do through ``pulser-core[torch]``.  Waveform formulas are pinned by the reference's stored notebook outputs
+(tests/golden/notebook_pins.json): Blackman, Ramp, Constant, Custom.  (Kaiser is provided but unpinned.)
+
+When the real Pulser is installed, ``TorchEmulator.from_sequence`` also accepts a genuine ``pulser.Sequence``
+through ``pulser_diff_amd.pulser_adapter``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field, replace
+from typing import Any, Iterable, Optional, Sequence as Seq, Union
+
+import numpy as np
+import torch
+from torch import Tensor
+
+RD = torch.float64
+
+
+def _t(v: Any) -> Tensor:
+    return v.to(RD) if isinstance(v, Tensor) else torch.as_tensor(v, dtype=RD)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# device / register
+# ---------------------------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class Device:
+    """The two device facts the hot path reads: ``interaction_coeff`` (hamiltonian.py:343) and basis support."""
+
+    name: str = "MockDevice"
+    interaction_coeff: float = 5420158.53  # C6/hbar for Rydberg level 70, rad/us*um^6 (pinned by KA-1..KA-5)
+    supported_bases: frozenset = frozenset({"ground-rydberg"})
+    supports_slm_mask: bool = False
+    max_atom_num: Optional[int] = None
+
+    def validate_register(self, register: "Register") -> None:
+        if self.max_atom_num is not None and len(register.qubit_ids) > self.max_atom_num:
+            raise ValueError(f"The number of atoms ({len(register.qubit_ids)}) exceeds the device maximum.")
+
+
+MockDevice = Device()
+
+
+class Register:
+    """Ordered mapping qubit id -> coordinates (um); coordinates may be leaf tensors requiring grad."""
+
+    def __init__(self, qubits: dict):
+        if not qubits:
+            raise ValueError("Cannot create a Register with an empty qubit dictionary.")
+        self._coords = {k: _t(v).reshape(-1) for k, v in qubits.items()}
+        dims = {c.numel() for c in self._coords.values()}
+        if len(dims) != 1 or dims.pop() not in (2, 3):
+            raise ValueError("All coordinates must be 2- or 3-dimensional.")
+
+    @property
+    def qubits(self) -> dict:
+        return dict(self._coords)
+
+    @property
+    def qubit_ids(self) -> tuple:
+        return tuple(self._coords)
+
+    @classmethod
+    def from_coordinates(cls, coords, prefix: str = "q") -> "Register":
+        return cls({f"{prefix}{i}": c for i, c in enumerate(coords)})
+
+    @classmethod
+    def rectangle(cls, rows: int, columns: int, spacing: float = 4.0, prefix: str = "q") -> "Register":
+        # pulser Register.rectangle: column index fastest, centred on the origin
+        coords = np.array([[c, r] for r in range(rows) for c in range(columns)], dtype=float) * spacing
+        coords -= coords.mean(axis=0)
+        return cls.from_coordinates(coords, prefix)
+
+    @classmethod
+    def square(cls, side: int, spacing: float = 4.0, prefix: str = "q") -> "Register":
+        return cls.rectangle(side, side, spacing, prefix)
+
+    def __repr__(self) -> str:
+        return f"Register({self._coords})"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# waveforms (per-ns samples in rad/us)
+# ---------------------------------------------------------------------------------------------------------------
+class Waveform:
+    def __init__(self, duration: int):
+        duration = int(duration)
+        if duration <= 0:
+            raise ValueError("A waveform must have a positive duration.")
+        self.duration = duration
+
+    @property
+    def samples(self) -> Tensor:  # pragma: no cover - abstract
+        raise NotImplementedError
+
+    @property
+    def integral(self) -> Tensor:
+        return self.samples.sum() * 1e-3
+
+
+class ConstantWaveform(Waveform):
+    def __init__(self, duration: int, value):
+        super().__init__(duration)
+        self.value = _t(value).reshape(())
+
+    @property
+    def samples(self) -> Tensor:
+        return self.value * torch.ones(self.duration, dtype=RD)
+
+
+class RampWaveform(Waveform):
+    def __init__(self, duration: int, start, stop):
+        super().__init__(duration)
+        self.start, self.stop = _t(start).reshape(()), _t(stop).reshape(())
+
+    @property
+    def samples(self) -> Tensor:
+        k = torch.arange(self.duration, dtype=RD)
+        return self.start + (self.stop - self.start) * k / max(self.duration - 1, 1)
+
+
+class BlackmanWaveform(Waveform):
+    def __init__(self, duration: int, area):
+        super().__init__(duration)
+        self.area = _t(area).reshape(())
+
+    @property
+    def samples(self) -> Tensor:
+        win = torch.as_tensor(np.clip(np.blackman(self.duration), 0.0, np.inf), dtype=RD)
+        return win * (self.area / (win.sum() * 1e-3))
+
+
+class KaiserWaveform(Waveform):
+    """Kaiser window normalised to `area` (beta defaults to pulser's 14; NOT pinned by any stored output)."""
+
+    def __init__(self, duration: int, area, beta: float = 14.0):
+        super().__init__(duration)
+        self.area, self.beta = _t(area).reshape(()), float(beta)
+
+    @property
+    def samples(self) -> Tensor:
+        win = torch.as_tensor(np.kaiser(self.duration, self.beta), dtype=RD)
+        return win * (self.area / (win.sum() * 1e-3))
+
+
+class CustomWaveform(Waveform):
+    def __init__(self, samples):
+        s = _t(samples).reshape(-1)
+        super().__init__(s.numel())
+        self._samples = s
+
+    @property
+    def samples(self) -> Tensor:
+        return self._samples
+
+
+@dataclass
+class Pulse:
+    amplitude: Waveform
+    detuning: Waveform
+    phase: Any = 0.0
+    post_phase_shift: Any = 0.0
+
+    def __post_init__(self):
+        if self.amplitude.duration != self.detuning.duration:
+            raise ValueError("The duration of detuning and amplitude waveforms must match.")
+        self.phase = _t(self.phase).reshape(())
+
+    @property
+    def duration(self) -> int:
+        return self.amplitude.duration
+
+    @classmethod
+    def ConstantPulse(cls, duration: int, amplitude, detuning, phase, post_phase_shift=0.0) -> "Pulse":
+        return cls(ConstantWaveform(duration, amplitude), ConstantWaveform(duration, detuning), phase, post_phase_shift)
+
+    @classmethod
+    def ConstantDetuning(cls, amplitude: Waveform, detuning, phase, post_phase_shift=0.0) -> "Pulse":
+        return cls(amplitude, ConstantWaveform(amplitude.duration, detuning), phase, post_phase_shift)
+
+    @classmethod
+    def ConstantAmplitude(cls, amplitude, detuning: Waveform, phase, post_phase_shift=0.0) -> "Pulse":
+        return cls(ConstantWaveform(detuning.duration, amplitude), detuning, phase, post_phase_shift)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# sampled sequence (the object TorchEmulator is constructed from, backend.py:61-69)
+# ---------------------------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class _PulseTargetSlot:
+    ti: int
+    tf: int
+    targets: frozenset
+
+
+@dataclass(frozen=True)
+class ChannelInfo:
+    addressing: str  # "Global" | "Local"
+    basis: str = "ground-rydberg"
+
+
+@dataclass
+class ChannelSamples:
+    amp: Tensor
+    det: Tensor
+    phase: Tensor
+    slots: list = field(default_factory=list)
+
+    @property
+    def duration(self) -> int:
+        return int(self.amp.shape[0])
+
+    def extend_duration(self, new_duration: int) -> "ChannelSamples":
+        ext = new_duration - self.duration
+        if ext < 0:
+            raise ValueError("Can't extend samples to a lower duration.")
+        zero = torch.zeros(ext, dtype=RD)
+        last_phase = self.phase[-1:].detach() if self.duration else torch.zeros(1, dtype=RD)
+        return replace(self, amp=torch.cat([self.amp, zero]), det=torch.cat([self.det, zero]),
+                       phase=torch.cat([self.phase, last_phase.expand(ext)]))
+
+
+@dataclass(frozen=True)
+class _SlmMask:
+    targets: frozenset = frozenset()
+    end: int = 0
+
+
+@dataclass
+class SequenceSamples:
+    channels: list
+    samples_list: list
+    _ch_objs: dict
+    _slm_mask: _SlmMask = field(default_factory=_SlmMask)
+    _magnetic_field: Optional[Tensor] = None
+    _measurement: Optional[str] = None
+
+    @property
+    def channel_samples(self) -> dict:
+        return dict(zip(self.channels, self.samples_list))
+
+    @property
+    def max_duration(self) -> int:
+        return max((s.duration for s in self.samples_list), default=0)
+
+    @property
+    def used_bases(self) -> set:
+        return {self._ch_objs[ch].basis for ch, s in self.channel_samples.items() if s.slots}
+
+    @property
+    def _in_xy(self) -> bool:
+        return False
+
+    def extend_duration(self, new_duration: int) -> "SequenceSamples":
+        return replace(self, samples_list=[s.extend_duration(new_duration) for s in self.samples_list])
+
+    def to_nested_dict(self, all_local: bool = False, samples_type: str = "tensor") -> dict:
+        """{'Global': {basis: {amp,det,phase}}, 'Local': {basis: {qid: {amp,det,phase}}}} (hamiltonian.py:177)."""
+        d = self.max_duration
+        out: dict = {"Global": {}, "Local": {}}
+        for ch, cs in self.channel_samples.items():
+            info = self._ch_objs[ch]
+            cs = cs.extend_duration(d)
+            if info.addressing == "Global" and not all_local:
+                g = out["Global"].setdefault(info.basis, {q: torch.zeros(d, dtype=RD) for q in ("amp", "det", "phase")})
+                for q in ("amp", "det", "phase"):
+                    g[q] = g[q] + getattr(cs, q)
+            else:
+                loc = out["Local"].setdefault(info.basis, {})
+                for slot in cs.slots:
+                    for qid in slot.targets:
+                        e = loc.setdefault(qid, {q: torch.zeros(d, dtype=RD) for q in ("amp", "det", "phase")})
+                        mask = torch.zeros(d, dtype=RD)
+                        mask[slot.ti:slot.tf] = 1.0
+                        for q in ("amp", "det", "phase"):
+                            e[q] = e[q] + getattr(cs, q) * mask
+        return out
+
+
+class Sequence:
+    """Pulse schedule on declared channels.  Channels run on independent timelines; `delay` inserts idle time."""
+
+    _CHANNELS = {"rydberg_global": ChannelInfo("Global"), "rydberg_local": ChannelInfo("Local")}
+
+    def __init__(self, register: Register, device: Device = MockDevice):
+        device.validate_register(register)
+        self.register = register
+        self.device = device
+        self._channels: dict[str, ChannelInfo] = {}
+        self._schedule: dict[str, list] = {}
+        self._targets: dict[str, frozenset] = {}
+        self._slm_mask_targets: set = set()
+
+    @property
+    def declared_channels(self) -> dict:
+        return dict(self._channels)
+
+    def declare_channel(self, name: str, channel_id: str, initial_target=None) -> None:
+        if name in self._channels:
+            raise ValueError("The given name is already in use.")
+        if channel_id not in self._CHANNELS:
+            raise ValueError(f"Channel {channel_id!r} is not supported by this backend (ground-rydberg only).")
+        info = self._CHANNELS[channel_id]
+        self._channels[name] = info
+        self._schedule[name] = []
+        if info.addressing == "Global":
+            self._targets[name] = frozenset(self.register.qubit_ids)
+        else:
+            self._targets[name] = frozenset()
+            if initial_target is not None:
+                self.target(initial_target, name)
+
+    def target(self, qubits, channel: str) -> None:
+        if self._channels[channel].addressing != "Local":
+            raise ValueError("Can only choose target of 'Local' channels.")
+        q = {qubits} if isinstance(qubits, (str, int)) else set(qubits)
+        if not q <= set(self.register.qubit_ids):
+            raise ValueError("All given ids have to be qubit ids declared in this sequence's register.")
+        self._targets[channel] = frozenset(q)
+
+    def add(self, pulse: Pulse, channel: str, protocol: str = "min-delay") -> None:
+        if channel not in self._channels:
+            raise ValueError("Use the name of a declared channel.")
+        if not self._targets[channel]:
+            raise ValueError("Local channel has no target: call `target` first.")
+        self._schedule[channel].append(("pulse", pulse, self._targets[channel]))
+
+    def delay(self, duration: int, channel: str) -> None:
+        self._schedule[channel].append(("delay", int(duration), self._targets[channel]))
+
+    def get_duration(self, channel: Optional[str] = None, include_fall_time: bool = False) -> int:
+        chans = [channel] if channel else list(self._channels)
+        return max((sum(it[1].duration if it[0] == "pulse" else it[1] for it in self._schedule[c]) for c in chans),
+                   default=0)
+
+    def is_parametrized(self) -> bool:
+        return False
+
+    def is_register_mappable(self) -> bool:
+        return False
+
+
+def sample(sequence: Sequence, modulation: bool = False, extended_duration: Optional[int] = None) -> SequenceSamples:
+    """pulser.sampler.sample restated for the supported subset (backend.py:701-705)."""
+    if modulation:
+        raise NotImplementedError("Output-modulated sampling is not supported by this backend.")
+    channels, samples_list = [], []
+    for name, items in sequence._schedule.items():
+        amps, dets, phases, slots = [], [], [], []
+        t = 0
+        for kind, obj, targets in items:
+            if kind == "pulse":
+                d = obj.duration
+                amps.append(obj.amplitude.samples)
+                dets.append(obj.detuning.samples)
+                phases.append(obj.phase * torch.ones(d, dtype=RD))
+                slots.append(_PulseTargetSlot(t, t + d, targets))
+            else:
+                d = obj
+                for lst in (amps, dets, phases):
+                    lst.append(torch.zeros(d, dtype=RD))
+            t += d
+        empty = torch.zeros(0, dtype=RD)
+        cs = ChannelSamples(torch.cat(amps) if amps else empty, torch.cat(dets) if dets else empty,
+                            torch.cat(phases) if phases else empty, slots)
+        channels.append(name)
+        samples_list.append(cs)
+    out = SequenceSamples(channels, samples_list, dict(sequence._channels))
+    total = max(out.max_duration, extended_duration or 0)
+    return out.extend_duration(total)

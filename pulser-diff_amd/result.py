@@ -1,0 +1,71 @@
+"""``TorchResult``: one state of a simulation run, same fields as ``pulser_diff/result.py:28-44`` (without the
+``pulser.result.Result`` base class, whose sampling helpers are restated here)."""
+from __future__ import annotations
+
+from collections import Counter
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+from torch import Tensor
+
+
+@dataclass
+class TorchResult:
+    """Represents the result of a run as a torch tensor.
+
+    Args:
+        atom_order: The order of the atoms in the bitstrings that represent the measured states.
+        meas_basis: The measurement basis.
+        state: The state: a ket of shape (dim, B) (B = 1 by default, ``result.py:54-59``).
+        matching_meas_basis: Whether the measurement basis is the same as the state's basis.
+    """
+
+    atom_order: tuple
+    meas_basis: str
+    state: Tensor
+    matching_meas_basis: bool
+
+    @property
+    def _size(self) -> int:
+        return len(self.atom_order)
+
+    @property
+    def _dim(self) -> int:
+        return 2
+
+    @property
+    def _basis_name(self) -> str:
+        if not self.matching_meas_basis:
+            return "digital" if self.meas_basis == "ground-rydberg" else "ground-rydberg"
+        return self.meas_basis
+
+    def _weights(self) -> Tensor:
+        """result.py:70-120 for two-level kets: probabilities in the measurement's bitstring order."""
+        probs = (torch.abs(self.state.detach()[:, 0]) ** 2).flatten().cpu()
+        if self.matching_meas_basis:
+            # state ordered with r first ([rr, rg, gr, gg] -> [11, 10, 01, 00]); invert to [00, 01, 10, 11]
+            weights = probs.flip(0) if self.meas_basis == "ground-rydberg" else probs
+        else:
+            weights = torch.zeros(probs.shape, dtype=probs.dtype)
+            weights[0] = 1.0
+        return weights / weights.sum()
+
+    @property
+    def sampling_dist(self) -> dict:
+        w = self._weights().numpy()
+        return {np.binary_repr(i, self._size): float(p) for i, p in enumerate(w) if p != 0}
+
+    @property
+    def sampling_errors(self) -> dict:
+        """result.py:46-52."""
+        return {bitstr: 0.0 for bitstr in self.sampling_dist}
+
+    def get_samples(self, n_samples: int) -> Counter:
+        w = self._weights().numpy().astype(np.float64)
+        counts = np.random.multinomial(n_samples, w / w.sum())
+        return Counter({np.binary_repr(i, self._size): int(c) for i, c in enumerate(counts) if c > 0})
+
+    def get_state(self, reduce_to_basis=None, ignore_global_phase: bool = True, tol: float = 1e-6,
+                  normalize: bool = True) -> Tensor:
+        raise NotImplementedError("Not rewritten with torch")  # result.py:150

@@ -1,0 +1,117 @@
+"""Results containers with the reference's semantics (``pulser_diff/simresults.py``): ``.states`` is a tensor of
+shape (n_t, dim, B) (``simresults.py:398-401``), ``.expect(obs_list)`` returns one (n_t,) tensor per observable
+(``simresults.py:81-129``), indexing / iteration yields per-time ``TorchResult`` objects.
+
+States live on the GPU as ONE (n_t, B, dim) buffer written by the native solver; ``.states`` is its permuted view
+and the per-time results are views into it (the reference stacks a Python list of per-time tensors).
+Diagonal observables that were handed to ``TorchEmulator.run(observables=...)`` are evaluated by the native
+``k_expect_diag`` kernel and returned from ``expect`` without touching the states.
+"""
+from __future__ import annotations
+
+import collections.abc
+from abc import ABC, abstractmethod
+from collections import Counter
+from typing import Mapping, Optional
+
+import torch
+from torch import Tensor
+
+from .result import TorchResult
+from .utils import DiagonalObservable, expect
+
+
+class SimulationResults(ABC):
+    """Results of a simulation run of a pulse sequence (parent of CoherentResults)."""
+
+    _use_pseudo_dens: bool = False
+
+    def __init__(self, size: int, basis_name: str, sim_times: Tensor) -> None:
+        self._dim = 3 if basis_name == "all" else 2
+        self._size = size
+        if basis_name not in {"ground-rydberg", "digital", "all", "XY"}:
+            raise ValueError("`basis_name` must be 'ground-rydberg', 'digital', 'all' or 'XY'.")
+        self._basis_name = basis_name
+        self._sim_times = sim_times
+
+    @property
+    @abstractmethod
+    def states(self) -> Tensor:
+        ...
+
+    def _get_index_from_time(self, t_float: float, tol: float = 1.0e-3) -> int:
+        """simresults.py:167-181."""
+        try:
+            return int(torch.where(abs(t_float - self._sim_times.detach().cpu()) < tol)[0][0])
+        except IndexError:
+            raise IndexError(f"Given time {t_float} is absent from Simulation times within" + f" tolerance {tol}.")
+
+
+class CoherentResults(SimulationResults, collections.abc.Sequence):
+    """Results of a coherent simulation run (``simresults.py:347-396``)."""
+
+    def __init__(self, states_tbd: Tensor, size: int, basis_name: str, sim_times: Tensor, meas_basis: str,
+                 meas_errors: Optional[Mapping[str, float]] = None, atom_order: tuple = (),
+                 native_expect: Optional[Tensor] = None, native_observables: Optional[list] = None,
+                 stats: Optional[dict] = None) -> None:
+        super().__init__(size, basis_name, sim_times)
+        if meas_basis != self._basis_name:
+            raise ValueError("`meas_basis` and `basis_name` must have the same value.")
+        if meas_errors is not None:
+            raise NotImplementedError("Measurement errors (SPAM) are not implemented in the MI355X-native backend.")
+        self._meas_basis = meas_basis
+        self._meas_errors = meas_errors
+        self._states_tbd = states_tbd  # (n_t, B, dim), possibly empty when states were not stored
+        self._atom_order = atom_order
+        self._native_expect = native_expect  # (n_obs, n_t, B)
+        self._native_observables = list(native_observables or [])
+        self.solver_stats = dict(stats or {})
+
+    # ---- sequence protocol over per-time results (pulser.result.Results)
+    def __len__(self) -> int:
+        return int(self._sim_times.shape[0])
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if self._states_tbd.numel() == 0:
+            raise RuntimeError("States were not stored for this run (store_states=False).")
+        return TorchResult(self._atom_order, self._meas_basis, self._states_tbd[i].transpose(0, 1), True)
+
+    @property
+    def states(self) -> Tensor:
+        """(n_t, dim, B) like ``torch.stack([res.state for res in self])`` (``simresults.py:398-401``)."""
+        if self._states_tbd.numel() == 0:
+            raise RuntimeError("States were not stored for this run (store_states=False).")
+        return self._states_tbd.permute(0, 2, 1)
+
+    def get_state(self, t: float, reduce_to_basis=None, ignore_global_phase: bool = True, tol: float = 1e-6,
+                  normalize: bool = True, t_tol: float = 1.0e-3) -> Tensor:
+        return self[self._get_index_from_time(t, t_tol)].get_state(reduce_to_basis, ignore_global_phase, tol, normalize)
+
+    def get_final_state(self, *args, **kwargs) -> Tensor:
+        return self.get_state(float(self._sim_times[-1]), *args, **kwargs)
+
+    def expect(self, obs_list) -> list:
+        """simresults.py:81-129."""
+        if not isinstance(obs_list, (list, Tensor)):
+            raise TypeError("`obs_list` must be a list of operators.")
+        legal_shape = (self._dim**self._size, self._dim**self._size)
+        out = []
+        for obs in obs_list:
+            if not isinstance(obs, (Tensor, DiagonalObservable)):
+                raise TypeError(f"Incompatible type {type(obs)} of observable. Type must be ArrayLike or qutip.Qobj.")
+            if tuple(obs.shape) != legal_shape:
+                raise ValueError("Incompatible shape of observable." + f"Expected {legal_shape}, got {tuple(obs.shape)}.")
+            hit = [k for k, o in enumerate(self._native_observables) if o is obs]
+            if hit and self._native_expect is not None:
+                out.append(self._native_expect[hit[0]].sum(dim=-1).to(torch.complex128))
+                continue
+            out.append(expect(obs, self.states))
+        return out
+
+    def sample_state(self, t: float, n_samples: int = 1000, t_tol: float = 1.0e-3) -> Counter:
+        return self[self._get_index_from_time(t, t_tol)].get_samples(n_samples)
+
+    def sample_final_state(self, N_samples: int = 1000) -> Counter:
+        return self.sample_state(float(self._sim_times[-1]), N_samples)

@@ -1,0 +1,222 @@
+"""CPU-only tests of the product's host logic and of the C-ABI library's host-side entry points
+(no compute calls: there is no GPU here)."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+import pulser_diff_amd as P
+from oracle import restatement as R
+from pulser_diff_amd import _native, pulses as pl
+from pulser_diff_amd.solver import SolverType, tolerance_from_options
+from tests.helpers import random_terms
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    header = (ROOT / "include" / "rydiff.h").read_text()
+    declared = set(re.findall(r"\b(rydiff_[a-z_]+)\s*\(", header))
+    assert declared == set(_native.EXPORTS), declared ^ set(_native.EXPORTS)
+    lib = _native.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.rydiff_version()
+
+
+def test_header_is_plain_c_and_struct_layouts_match_ctypes(tmp_path):
+    """The ABI header must compile as C (gcc) and the ctypes mirrors must have the same size and field offsets."""
+    import subprocess
+
+    src = tmp_path / "layout.c"
+    fields_p = [f[0] for f in _native.RydProblem._fields_]
+    fields_i = [f[0] for f in _native.RydPlanInfo._fields_]
+    nl = chr(92) + "n"  # a literal backslash-n inside the C string
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT / "include" / "rydiff.h"}"', "int main(void){",
+             f'printf("%zu %zu{nl}", sizeof(RydProblem), sizeof(RydPlanInfo));']
+    lines += [f'printf("%zu{nl}", offsetof(RydProblem, {f}));' for f in fields_p]
+    lines += [f'printf("%zu{nl}", offsetof(RydPlanInfo, {f}));' for f in fields_i]
+    lines += ["return 0;}"]
+    src.write_text(chr(10).join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert int(out[0]) == ctypes.sizeof(_native.RydProblem) and int(out[1]) == ctypes.sizeof(_native.RydPlanInfo)
+    offs = [int(v) for v in out[2:]]
+    assert offs[:len(fields_p)] == [getattr(_native.RydProblem, f).offset for f in fields_p]
+    assert offs[len(fields_p):] == [getattr(_native.RydPlanInfo, f).offset for f in fields_i]
+
+
+@pytest.mark.parametrize("rho", [1e-3, 0.05, 0.5, 1.3, 3.0, 6.0])
+@pytest.mark.parametrize("tol", [1e-13, 1e-9])
+def test_polynomial_design_matches_numpy_chebyshev_roots_and_exponential(rho, tol):
+    import scipy.special as sp
+    from numpy.polynomial import chebyshev as C
+
+    roots, p0, err = _native.design_polynomial(rho, tol)
+    m = len(roots)
+    a = np.array([(1 if k == 0 else 2) * (-1j) ** k * sp.jv(k, rho) for k in range(m + 1)])
+    ref = C.chebroots(a)
+    for z in roots:
+        assert np.abs(ref - z).min() < 1e-8 * abs(z)
+    assert (np.abs(roots)[:-1] >= np.abs(roots)[1:] - 1e-12).all()  # sorted by decreasing modulus
+    x = np.cos(np.linspace(0, np.pi, 401))
+    p = np.full_like(x, p0, dtype=complex)
+    partial_max = 0.0
+    for z in roots:
+        p = p * (1 - x / z)
+        partial_max = max(partial_max, np.abs(p).max())
+    assert np.abs(p - np.exp(-1j * rho * x)).max() < 50 * tol + 1e-13
+    assert partial_max < 2.0  # the ordering keeps every partial product O(1): no cancellation blow-up
+    assert err < 50 * tol + 1e-13
+
+
+def test_product_form_pipeline_model_forward_and_adjoint():
+    """numpy model of what the device does factor by factor (y = gamma x + beta H x) and of the exact discrete
+    adjoint with its gradient contractions, against torch autograd through the oracle's dense matrix_exp."""
+    terms = random_terms(4, 9, 0.004, seed=11, local=False)
+    t = torch.tensor(0.012, dtype=torch.float64)
+    amp = terms.amp_coeff.clone().requires_grad_(True)
+    det = terms.det_coeff.clone().requires_grad_(True)
+    tm = R.HamTerms(4, terms.u_pairs, amp, det, terms.dt, terms.n_samples, terms.amp_targets, terms.det_targets)
+    H = R.dense_hamiltonian(tm, t)
+    tau = 0.004
+    psi0 = torch.randn(16, dtype=torch.complex128, generator=torch.Generator().manual_seed(1))
+    psi0 = psi0 / psi0.norm()
+    w = torch.randn(16, dtype=torch.complex128, generator=torch.Generator().manual_seed(2))
+    psi1 = torch.linalg.matrix_exp(-1j * H * tau) @ psi0
+    loss = (w.conj() * psi1).sum().real
+    loss.backward()
+
+    Hn = H.detach().numpy()
+    ev = np.linalg.eigvalsh(Hn)
+    lo, hi = ev.min() - 3.0, ev.max() + 3.0
+    sigma, width = (hi + lo) / 2, (hi - lo) / 2
+    rho = tau * width
+    roots, p0, _ = _native.design_polynomial(rho, 1e-13)
+    gam = 1 + tau * sigma / (rho * roots)
+    bet = -tau / (rho * roots)
+    kappa = np.exp(-1j * tau * sigma) * p0
+    gam[-1] *= kappa
+    bet[-1] *= kappa
+    xs = [psi0.numpy()]
+    for g_, b_ in zip(gam, bet):
+        xs.append(g_ * xs[-1] + b_ * (Hn @ xs[-1]))
+    assert np.abs(xs[-1] - psi1.detach().numpy()).max() < 1e-12
+    # adjoint sweep; global drive => one coefficient group: contractions summed over all qubits
+    lam = w.numpy().copy()
+    idx = np.arange(16)
+    g_cre = g_cim = g_d = 0.0
+    occ = R.occupation_table(4).numpy().sum(0)
+    for f in range(len(roots) - 1, -1, -1):
+        a_ = bet[f] * np.conj(lam)
+        for j in range(4):
+            m = 1 << (3 - j)
+            b1 = (idx & m) != 0
+            t1 = (a_[b1] * xs[f][idx[b1] ^ m]).sum()
+            t0 = (a_[~b1] * xs[f][idx[~b1] ^ m]).sum()
+            g_cre += (t1 + t0).real
+            g_cim += -(t1 - t0).imag
+        g_d += (occ * (a_ * xs[f]).real).sum()
+        lam = np.conj(gam[f]) * lam + np.conj(bet[f]) * (Hn @ lam)
+    # chain to the table entries through the interpolation weights (hamiltonian.py:538,542)
+    i1, i2 = R.interp_indices(float(t), terms.dt, terms.n_samples)
+    frac = (float(t) - i1 * terms.dt) / terms.dt
+    ref_amp = amp.grad.numpy()
+    assert abs((1 - frac) * (g_cre + 1j * g_cim) - ref_amp[i1]) < 1e-10 * max(1, abs(ref_amp[i1]))
+    assert abs(frac * (g_cre + 1j * g_cim) - ref_amp[i2]) < 1e-10 * max(1, abs(ref_amp[i2]))
+    assert abs(2 * (1 - frac) * g_d - det.grad.numpy()[i1]) < 1e-10 * max(1, abs(det.grad.numpy()[i1]))
+
+
+def _ka1_emulator():
+    reg = pl.Register({"q0": [0.0, 0.0], "q1": [0.0, 8.0], "q2": [8.0, 0.0], "q3": [8.0, 8.0]})
+    seq = pl.Sequence(reg, pl.MockDevice)
+    seq.declare_channel("rydberg_global", "rydberg_global")
+    seq.add(pl.Pulse(pl.BlackmanWaveform(800, torch.pi), pl.RampWaveform(800, -5.0, 0.0), 0), "rydberg_global")
+    seq.add(pl.Pulse.ConstantPulse(800, 5.0, 0.0, 0.0), "rydberg_global")
+    return P.TorchEmulator.from_sequence(seq, sampling_rate=0.1, compute_device="cpu")
+
+
+def test_emulator_tables_times_and_hamiltonian_match_the_oracle():
+    sim = _ka1_emulator()
+    oseq = R.concat_pulses([(R.blackman_waveform(800, np.pi), R.ramp_waveform(800, -5.0, 0.0), 0.0),
+                            (R.constant_waveform(800, 5.0), R.constant_waveform(800, 0.0), 0.0)])
+    ot = R.build_terms(oseq, torch.tensor([[0, 0], [0, 8], [8, 0], [8, 8]], dtype=torch.float64), 0.1)
+    ham = sim._hamiltonian
+    assert torch.equal(sim.evaluation_times, R.evaluation_times(1600, 0.1))
+    assert torch.equal(sim.sampling_times, R.sampling_times(1600, 0.1))
+    assert (ham.amp_tables[0, 0] - ot.amp_coeff).abs().max() < 1e-14
+    assert (ham.det_tables[0, 0] - ot.det_coeff).abs().max() < 1e-14
+    assert (ham.u_pairs - ot.u_pairs).abs().max() < 1e-12
+    assert ham.n_samples == ot.n_samples == 160 and abs(ham.dt - 0.01) < 1e-15
+    assert ham.amp_masks == (0b1111,) and ham.det_masks == (0b1111,)
+    for t_ns in (0, 333, 800, 1600):
+        d = sim.get_hamiltonian(t_ns).to_dense() - R.dense_hamiltonian(ot, torch.tensor(t_ns / 1000, dtype=torch.float64))
+        assert d.abs().max() < 1e-12
+    assert sim.endtimes == [0, 79, 80, 158, 159]
+    assert sim.initial_state.shape == (16, 1) and sim.initial_state[-1, 0] == 1
+    assert sim.dim == 2 and sim.basis_name == "ground-rydberg"
+
+
+def test_emulator_local_channel_terms_follow_reference_order():
+    reg = pl.Register.rectangle(1, 3, spacing=8)
+    seq = pl.Sequence(reg, pl.MockDevice)
+    seq.declare_channel("g", "rydberg_global")
+    seq.declare_channel("l", "rydberg_local", initial_target="q1")
+    seq.add(pl.Pulse.ConstantPulse(100, 3.0, 1.0, 0.2), "g")
+    seq.add(pl.Pulse.ConstantPulse(60, 2.0, 0.0, 0.0), "l")
+    seq.target(["q0", "q2"], "l")
+    seq.add(pl.Pulse.ConstantPulse(40, 0.0, -2.0, 0.0), "l")
+    sim = P.TorchEmulator.from_sequence(seq, compute_device="cpu")
+    ham = sim._hamiltonian
+    # Global first (amp, det), then Local per qubit (hamiltonian.py:487-490, 435-452)
+    assert ham.amp_masks == (0b111, 0b010)
+    assert ham.det_masks == (0b111, 0b001, 0b100)
+    assert ham.amp_tables.shape == (1, 2, 101) and ham.det_tables.shape == (1, 3, 101)
+    assert abs(ham.amp_tables[0, 1, 10].item() - 1.0) < 1e-15 and ham.amp_tables[0, 1, 70].item() == 0
+    assert abs(ham.det_tables[0, 1, 80].item() - 1.0) < 1e-15
+
+
+def test_emulator_validation_errors_match_the_reference():
+    sim = _ka1_emulator()
+    with pytest.raises(ValueError, match="Incompatible shape of initial state"):
+        sim.set_initial_state(torch.zeros(8))
+    with pytest.raises(ValueError, match="extends further than sequence duration"):
+        sim.set_evaluation_times([0.1, 5.0])
+    with pytest.raises(ValueError, match="negative values"):
+        sim.set_evaluation_times([-0.1, 0.5])
+    with pytest.raises(ValueError, match="Wrong evaluation time label"):
+        sim.set_evaluation_times("Sometimes")
+    with pytest.raises(ValueError, match="must be less than or equal to the sequence duration"):
+        sim.get_hamiltonian(5000)
+    with pytest.raises(TypeError):
+        P.TorchEmulator("not samples", None, pl.MockDevice)
+    with pytest.raises(TypeError):
+        P.TorchEmulator.from_sequence("not a sequence")
+    with pytest.raises(NotImplementedError):
+        sim.set_config(P.SimConfig(noise="dephasing"))
+    sim.set_evaluation_times("Minimal")
+    assert sim.evaluation_times.tolist() == [0.0, 1.6]
+    sim.set_evaluation_times(0.5)
+    assert torch.equal(sim.evaluation_times, R.evaluation_times(1600, 0.1, 0.5)) and len(sim.evaluation_times) == 80
+
+
+def test_product_path_fails_loudly_without_gpu_and_never_touches_the_oracle():
+    sim = _ka1_emulator()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        sim.run(solver=SolverType.KRYLOV_SE)
+    # no module of the product imports the oracle
+    for path in (ROOT / "pulser-diff_amd").rglob("*.py"):
+        txt = path.read_text()
+        assert "import oracle" not in txt and "from oracle" not in txt, path
+
+
+def test_solver_options_mapping():
+    assert tolerance_from_options({}) == 0.0
+    assert tolerance_from_options({"tol": 1e-10}) == 1e-10
+    assert tolerance_from_options({"atol": 1e-10, "rtol": 1e-8}) == pytest.approx(1e-12)
+    with pytest.raises(TypeError):
+        tolerance_from_options({"bogus": 1})

@@ -1,0 +1,133 @@
+"""The CPU oracle against every static numerical pin the reference holds for this path: the stored outputs of
+docs/basic_usage.ipynb (tests/golden/notebook_pins.json).
+
+Tolerances = print precision of the stored outputs (4 decimals -> 1e-4 (+DP5 error), 6-decimal loss traces -> 1e-6).
+These validate conventions (C6, basis order, waveform normalisation, sampling-grid quirks, right-endpoint Krylov
+rule) and gradient correctness; the 1e-8 parity bar is then GPU-vs-oracle (tests/test_gpu_*.py).
+"""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import restatement as R
+
+PINS = json.loads((Path(__file__).parent / "golden" / "notebook_pins.json").read_text())
+F32_PI = torch.tensor([torch.pi])  # the notebook's leaves are float32 tensors
+
+
+def _square4():
+    return torch.tensor([[0, 0], [0, 8], [8, 0], [8, 8]], dtype=torch.float64)
+
+
+def _ka1_problem():
+    # basic_usage.ipynb cells 7-12: Blackman(800, pi)/Ramp(800,-5,0) then Constant(800, 5, 0, 0); sampling_rate 0.1
+    seq = R.concat_pulses([(R.blackman_waveform(800, F32_PI[0]), R.ramp_waveform(800, torch.tensor(-5.0), 0.0), 0.0),
+                           (R.constant_waveform(800, torch.tensor(5.0)), R.constant_waveform(800, 0.0), 0.0)])
+    terms = R.build_terms(seq, _square4(), 0.1)
+    return seq, terms, R.evaluation_times(seq.tot_duration, 0.1)
+
+
+def test_ka1_evaluation_times_reproduce_irregular_grid():
+    _, _, ts = _ka1_problem()
+    assert len(ts) == 160
+    assert np.abs(ts.numpy() - np.array(PINS["ka1_eval_times"])).max() < 5e-5  # printed with 4 decimals
+
+
+def test_ka1_dp5_expectation_series_and_printed_amplitudes():
+    _, terms, ts = _ka1_problem()
+    psi0 = R.all_ground_state(4).numpy()
+    states = R.dp5_solve(R.make_rhs(terms), psi0, ts.numpy())
+    zd = R.total_magnetization_diag(4).numpy()
+    ez = (np.abs(states[:, :, 0]) ** 2 * zd).sum(1)
+    assert np.abs(ez - np.array(PINS["ka1_sum_z"])).max() < 1.5e-4
+    # printed rows: for the first 3 and last 3 times, amplitudes [0,1,2] and [13,14,15]
+    rows = np.array(PINS["ka1_state_rows"])
+    rows = rows[:, 0] + 1j * rows[:, 1]
+    assert len(rows) == 36
+    for block, t_idx in enumerate([0, 1, 2, 157, 158, 159]):
+        got = states[t_idx, [0, 1, 2, 13, 14, 15], 0]
+        ref = rows[6 * block:6 * block + 6]
+        assert np.abs(got - ref).max() < 2e-5 + 1e-4 * np.abs(ref).max()
+    # the continuous solution (what DP5 approximates) agrees within DP5's default tolerance
+    cont = R.continuous_solution(terms, psi0, ts.numpy())
+    assert np.abs(cont - states).max() < 5e-5
+
+
+def _krylov_final_sum_z(pulses, coords, rate=0.5):
+    seq = R.concat_pulses(pulses)
+    terms = R.build_terms(seq, coords, rate)
+    ts = R.evaluation_times(seq.tot_duration, rate)
+    n = coords.shape[0]
+    st = R.krylov_map_dense(terms, R.all_ground_state(n), ts)
+    return R.expect(R.total_magnetization(n), st).real[-1]
+
+
+def _pulses_21(omega, area):
+    return [(R.constant_waveform(1000, omega), R.constant_waveform(1000, 0.0), 0.0),
+            (R.blackman_waveform(800, area), R.ramp_waveform(800, 5.0, 0.0), 0.0)]
+
+
+def test_ka2_ka3_ka4_krylov_right_endpoint_values():
+    pair = torch.tensor([[-4.0, 0.0], [4.0, 0.0]], dtype=torch.float64)  # Register.rectangle(1, 2, spacing=8)
+    e2 = _krylov_final_sum_z(_pulses_21(torch.tensor(5.0), F32_PI[0]), pair)
+    assert abs(e2.item() - PINS["ka2_pulse_opt"]["initial_expectation"]) < 6e-5
+    coords3 = torch.tensor([[0.5, 0.4], [8.3, 0.1]]).to(torch.float64)  # float32 leaves in the notebook
+    e3 = _krylov_final_sum_z(_pulses_21(torch.tensor(5.0), 3.14), coords3)
+    assert abs(e3.item() - PINS["ka3_register_opt"]["initial_expectation"]) < 6e-5
+    x = torch.arange(300) / 300
+    wf = torch.tensor(6.0) * torch.sin(torch.pi * x) * torch.exp(-torch.tensor(2.0) * x)
+    e4 = _krylov_final_sum_z(_pulses_21(torch.tensor(5.0), F32_PI[0]) + [(wf, R.constant_waveform(300, 1.5), 0.0)], pair)
+    assert abs(e4.item() - PINS["ka4_shape_opt"]["initial_expectation"]) < 6e-5
+
+
+def _adam_trace(params, model, lr, n_iter, clamp=None):
+    opt = torch.optim.Adam(params, lr=lr)
+    target = torch.tensor(-0.5, dtype=torch.float64)
+    losses = []
+    for _ in range(n_iter):
+        loss = torch.nn.functional.mse_loss(model(), target)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        if clamp is not None:
+            with torch.no_grad():
+                clamp()
+        losses.append(loss.item())
+        if loss.item() < 1e-5:
+            break
+    return losses
+
+
+def test_ka5_adam_loss_trace_pins_gradients_wrt_pulse_parameters():
+    """basic_usage.ipynb section 2.1: 33 printed losses; from step 2 on they depend on gradient ratios."""
+    omega = torch.tensor([5.0], requires_grad=True)
+    area = torch.tensor([torch.pi], requires_grad=True)
+    pair = torch.tensor([[-4.0, 0.0], [4.0, 0.0]], dtype=torch.float64)
+    losses = _adam_trace([area, omega], lambda: _krylov_final_sum_z(_pulses_21(omega[0], area[0]), pair), 0.05, 100,
+                         clamp=lambda: omega.clamp_(4.5, 5.5))
+    ref = PINS["ka2_pulse_opt"]["losses"]
+    assert len(losses) == len(ref) == 33
+    assert np.abs(np.array(losses) - np.array(ref)).max() < 1.5e-6
+    assert abs(area.item() - 2.5058) < 1e-4 and abs(omega.item() - 4.6157) < 1e-4  # printed parameters
+
+
+def test_ka5_adam_loss_trace_pins_gradients_wrt_coordinates():
+    """basic_usage.ipynb section 2.2: omega and both qubits' coordinates trainable (53 printed losses)."""
+    omega = torch.tensor([5.0], requires_grad=True)
+    q0 = torch.tensor([0.5, 0.4], requires_grad=True)
+    q1 = torch.tensor([8.3, 0.1], requires_grad=True)
+
+    def model():
+        coords = torch.stack([q0, q1]).to(torch.float64)
+        seq = R.concat_pulses(_pulses_21(omega[0], 3.14))
+        terms = R.build_terms(seq, coords, 0.5, u_pairs=R.C6_MOCK_DEVICE / torch.linalg.norm(coords[0] - coords[1]).reshape(1) ** 6)
+        ts = R.evaluation_times(seq.tot_duration, 0.5)
+        st = R.krylov_map_dense(terms, R.all_ground_state(2), ts)
+        return R.expect(R.total_magnetization(2), st).real[-1]
+
+    losses = _adam_trace([omega, q0, q1], model, 0.05, 20, clamp=lambda: omega.clamp_(4.5, 5.5))
+    ref = PINS["ka3_register_opt"]["losses"][:20]
+    assert np.abs(np.array(losses) - np.array(ref)).max() < 2e-6
