@@ -275,7 +275,7 @@ class SequenceSamples:
             else:
                 loc = out["Local"].setdefault(info.basis, {})
                 for slot in cs.slots:
-                    for qid in slot.targets:
+                    for qid in sorted(slot.targets, key=str):  # deterministic order
                         e = loc.setdefault(qid, {q: torch.zeros(d, dtype=RD) for q in ("amp", "det", "phase")})
                         mask = torch.zeros(d, dtype=RD)
                         mask[slot.ti:slot.tf] = 1.0
