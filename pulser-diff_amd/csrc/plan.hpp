@@ -228,7 +228,7 @@ inline size_t carve(Plan& pl, bool need_tape, bool need_backward, int chain_slot
     pl.chain_slots = chain_slots;
     if (need_backward) {
         pl.off_chain = take(size_t(chain_slots > 0 ? chain_slots : 1) * pl.state_bytes);
-        pl.off_ge = take(size_t(pl.Bc) * E * (pl.NC + 1) * sizeof(double));
+        pl.off_ge = take(size_t(pl.Bc) * E * 64 /* kGradReplicas */ * (pl.NC + 1) * sizeof(double));
         pl.off_wtot = take(pl.dim * sizeof(double));
         pl.off_meta2 = take(align_up(E * 4 * sizeof(double)) + align_up(E * 3 * sizeof(int32_t)) + align_up(E * sizeof(double)));
     }

@@ -30,6 +30,9 @@ using namespace rydiff;
 // ------------------------------------------------------------------------------------------------
 // error handling
 // ------------------------------------------------------------------------------------------------
+// gradient accumulators are replicated so that concurrent blocks do not serialise on one address
+constexpr int kGradReplicas = 64;
+
 static thread_local std::string g_last_error;
 static int g_kernel_variant = 0;
 
@@ -79,8 +82,9 @@ struct FactorBwdArgs {
     const double* udiag;
     const double* coef;
     long coef_bstride;
-    double* ge;           // gradient record of this exponential, trajectory 0: gcre[ga], gcim[ga], gd[gd], gtau
+    double* ge;           // gradient record of this exponential, trajectory 0, replica 0: gcre[ga], gcim[ga], gd[gd], gtau
     long ge_bstride;
+    long ge_rstride;      // doubles between replicas (NC+1)
     double* wtot;         // optional [dim]: accumulates Re(beta*conj(g)*x) for the U_ij gradient
     uint32_t dim;
     double gr, gi, br, bi;
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(256) void k_factor_bwd_direct(FactorBwdArgs a) {
     const double2* __restrict__ gin = a.gin + boff;
     const double2* __restrict__ xin = a.xin + boff;
     const double* __restrict__ cf = a.coef + blockIdx.y * a.coef_bstride;
-    double* __restrict__ ge = a.ge + blockIdx.y * a.ge_bstride;
+    double* __restrict__ ge = a.ge + blockIdx.y * a.ge_bstride + (blockIdx.x % kGradReplicas) * a.ge_rstride;
     const uint32_t xs = live ? x : 0u;
     const double d = diag_value(a.udiag, cf, a.g, xs);
     double2 gy = gin[xs];
@@ -374,6 +378,7 @@ struct DotHArgs {
     long coef_bstride;
     double* out;  // ge record + NC (gtau slot), trajectory 0
     long out_bstride;
+    long out_rstride;
     uint32_t dim;
     GroupArgs gr;
 };
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(256) void k_dot_hx(DotHArgs a) {
     const double2 g = (a.g + boff)[xs];
     // Im(conj(g) * h) = g.x*hi - g.y*hr
     const double val = live ? (g.x * hi - g.y * hr) : 0.0;
-    block_atomic_add(val, a.out + blockIdx.y * a.out_bstride, lds);
+    block_atomic_add(val, a.out + blockIdx.y * a.out_bstride + (blockIdx.x % kGradReplicas) * a.out_rstride, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -459,7 +464,7 @@ __global__ __launch_bounds__(256) void k_inject(double2* __restrict__ lam, const
 // one thread per (exponential, trajectory); atomics because several exponentials touch one sample.
 // ------------------------------------------------------------------------------------------------
 struct ScatterArgs {
-    const double* ge;       // [Bc][E][NC+1]
+    const double* ge;       // [Bc][E][kGradReplicas][NC+1]
     const int32_t* idx;     // [E][4]
     const double* w;        // [E][4]
     const double* dwdt;     // [E][4]
@@ -478,7 +483,13 @@ __global__ void k_scatter_grads(ScatterArgs a) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (e >= a.E) return;
-    const double* rec = a.ge + (size_t(b) * a.E + e) * (a.NC + 1);
+    const double* reps = a.ge + (size_t(b) * a.E + e) * kGradReplicas * (a.NC + 1);
+    double rec[2 * kMaxGroups + kMaxGroups + 1];
+    for (int c = 0; c <= a.NC; ++c) {
+        double sum = 0.0;
+        for (int r = 0; r < kGradReplicas; ++r) sum += reps[size_t(r) * (a.NC + 1) + c];  // fixed order
+        rec[c] = sum;
+    }
     double dLdt = 0.0;
     for (int k = 0; k < a.Ka; ++k) {
         double gr = 0.0, gi = 0.0;
@@ -882,12 +893,13 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
     const double* udiag = reinterpret_cast<const double*>(ws + pl.off_udiag);
     const double* coef = reinterpret_cast<const double*>(ws + pl.off_coef);
     const long coef_bstride = pl.Bc > 1 ? long(E) * pl.NC : 0;
-    const long ge_bstride = pl.Bc > 1 ? long(E) * (pl.NC + 1) : 0;
+    const long ge_rec = long(kGradReplicas) * (pl.NC + 1);
+    const long ge_bstride = pl.Bc > 1 ? long(E) * ge_rec : 0;
     const double2* gst = static_cast<const double2*>(grad_states);
     const double* obs = p->obs_diag;
     const bool have_gexp = grad_expect && pl.n_obs > 0;
 
-    HIP_TRY(hipMemsetAsync(ge, 0, size_t(pl.Bc) * E * (pl.NC + 1) * sizeof(double), stream));
+    HIP_TRY(hipMemsetAsync(ge, 0, size_t(pl.Bc) * E * ge_rec * sizeof(double), stream));
     if (wtot) HIP_TRY(hipMemsetAsync(wtot, 0, pl.dim * sizeof(double), stream));
     dim3 grid(unsigned((pl.dim + 255) / 256), pl.B);
     int cl = 0;
@@ -924,8 +936,9 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
                 da.udiag = udiag;
                 da.coef = coef + size_t(it.stage) * pl.NC;
                 da.coef_bstride = coef_bstride;
-                da.out = ge + size_t(it.stage) * (pl.NC + 1) + pl.NC;
+                da.out = ge + size_t(it.stage) * ge_rec + pl.NC;
                 da.out_bstride = ge_bstride;
+                da.out_rstride = pl.NC + 1;
                 da.dim = uint32_t(pl.dim);
                 da.gr = rt.garg;
                 hipLaunchKernelGGL(k_dot_hx, grid, dim3(256), 0, stream, da);
@@ -938,8 +951,9 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
             ba.udiag = udiag;
             ba.coef = coef + size_t(it.stage) * pl.NC;
             ba.coef_bstride = coef_bstride;
-            ba.ge = ge + size_t(it.stage) * (pl.NC + 1);
+            ba.ge = ge + size_t(it.stage) * ge_rec;
             ba.ge_bstride = ge_bstride;
+            ba.ge_rstride = pl.NC + 1;
             ba.wtot = wtot;
             ba.dim = uint32_t(pl.dim);
             ba.gr = it.s.gr;

@@ -1,0 +1,146 @@
+"""GPU tests through the user-facing surface (TorchEmulator / CoherentResults / deriv_*), against the reference's
+stored notebook outputs (golden fixture) and the CPU oracle."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+import pulser_diff_amd as P
+from oracle import restatement as R
+from pulser_diff_amd import pulses as pl
+from pulser_diff_amd.derivative import deriv_param, deriv_time
+from pulser_diff_amd.solver import SolverType
+from pulser_diff_amd.utils import DiagonalObservable, total_magnetization, total_magnetization_diag
+
+pytestmark = pytest.mark.gpu
+PINS = json.loads((Path(__file__).parent / "golden" / "notebook_pins.json").read_text())
+
+
+def _seq21(omega, area, coords=None, extra=None):
+    reg = pl.Register.rectangle(1, 2, spacing=8, prefix="q") if coords is None else pl.Register(coords)
+    seq = pl.Sequence(reg, pl.MockDevice)
+    seq.declare_channel("rydberg_global", "rydberg_global")
+    seq.add(pl.Pulse.ConstantPulse(1000, omega, 0.0, 0.0), "rydberg_global")
+    seq.add(pl.Pulse(pl.BlackmanWaveform(800, area), pl.RampWaveform(800, 5.0, 0.0), 0), "rydberg_global")
+    if extra is not None:
+        seq.add(extra, "rydberg_global")
+    return seq
+
+
+def test_notebook_krylov_values_through_the_emulator(cuda_device):
+    """KA-2, KA-3, KA-4: printed initial <sum Z>(T) of basic_usage.ipynb sections 2.1, 2.2, 2.4 (4 decimals)."""
+    obs = total_magnetization(2)
+    f32pi = torch.tensor([torch.pi])[0]
+    sim = P.TorchEmulator.from_sequence(_seq21(torch.tensor(5.0), f32pi), sampling_rate=0.5)
+    res = sim.run(solver=SolverType.KRYLOV_SE)
+    e = res.expect([obs])[0].real
+    assert abs(e[-1].item() - PINS["ka2_pulse_opt"]["initial_expectation"]) < 6e-5
+    assert res.states.shape == (len(sim.evaluation_times), 4, 1)
+    sim = P.TorchEmulator.from_sequence(_seq21(torch.tensor(5.0), 3.14, {"q0": torch.tensor([0.5, 0.4]), "q1": torch.tensor([8.3, 0.1])}),
+                                        sampling_rate=0.5)
+    e = sim.run(solver=SolverType.KRYLOV_SE).expect([obs])[0].real
+    assert abs(e[-1].item() - PINS["ka3_register_opt"]["initial_expectation"]) < 6e-5
+    x = torch.arange(300) / 300
+    wf = torch.tensor(6.0) * torch.sin(torch.pi * x) * torch.exp(-torch.tensor(2.0) * x)
+    extra = pl.Pulse(pl.CustomWaveform(wf), pl.ConstantWaveform(300, 1.5), 0.0)
+    sim = P.TorchEmulator.from_sequence(_seq21(torch.tensor(5.0), f32pi, extra=extra), sampling_rate=0.5)
+    e = sim.run(solver=SolverType.KRYLOV_SE).expect([obs])[0].real
+    assert abs(e[-1].item() - PINS["ka4_shape_opt"]["initial_expectation"]) < 6e-5
+
+
+def test_notebook_adam_trace_through_the_emulator(cuda_device):
+    """KA-5: the 33 printed Adam losses of basic_usage.ipynb section 2.1, with the native adjoint supplying the
+    gradients of <sum Z>(T) w.r.t. the float32 leaves omega and area (first 12 iterations to keep the test short)."""
+    omega = torch.tensor([5.0], requires_grad=True)
+    area = torch.tensor([torch.pi], requires_grad=True)
+    opt = torch.optim.Adam([area, omega], lr=0.05)
+    zobs = DiagonalObservable(total_magnetization_diag(2))
+    losses = []
+    for _ in range(12):
+        sim = P.TorchEmulator.from_sequence(_seq21(omega[0], area[0]), sampling_rate=0.5)
+        res = sim.run(solver=SolverType.KRYLOV_SE, observables=[zobs])
+        e = res.expect([zobs])[0].real
+        loss = torch.nn.functional.mse_loss(e[-1].cpu(), torch.tensor(-0.5, dtype=torch.float64))
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        with torch.no_grad():
+            omega.clamp_(4.5, 5.5)
+        losses.append(loss.item())
+    assert np.abs(np.array(losses) - np.array(PINS["ka2_pulse_opt"]["losses"][:12])).max() < 1.5e-6
+
+
+def test_deriv_param_and_deriv_time_against_oracle_autograd(cuda_device):
+    """derivative.py:26-78 on this backend's outputs: repeated VJPs with retain_graph=True (deriv_param), gradients
+    w.r.t. evaluation times (time_grad) and inter-qubit distances (dist_grad), vs autograd through the oracle."""
+    omega = torch.tensor(5.0, dtype=torch.float64, requires_grad=True)
+    area = torch.tensor(2.5, dtype=torch.float64, requires_grad=True)
+    coords = {"q0": torch.tensor([0.0, 0.0], dtype=torch.float64), "q1": torch.tensor([0.0, 8.0], dtype=torch.float64),
+              "q2": torch.tensor([7.0, 1.0], dtype=torch.float64, requires_grad=True)}
+    reg = pl.Register(coords)
+    seq = pl.Sequence(reg, pl.MockDevice)
+    seq.declare_channel("ch", "rydberg_global")
+    seq.add(pl.Pulse(pl.BlackmanWaveform(200, area), pl.RampWaveform(200, -4.0, 2.0), 0.3), "ch")
+    seq.add(pl.Pulse.ConstantPulse(100, omega, 1.0, 0.0), "ch")
+    sim = P.TorchEmulator.from_sequence(seq, sampling_rate=0.2)
+    res = sim.run(time_grad=True, dist_grad=True, solver=SolverType.KRYLOV_SE)
+    zdiag = total_magnetization_diag(3)
+    f = res.expect([DiagonalObservable(zdiag)])[0].real
+    times = sim.evaluation_times
+    r = sim.qq_distances["q0-q2"]
+    g_mid = deriv_param(f=f, x=[omega, area, coords["q2"], r], times=times, t=150)
+    g_end = deriv_param(f=f, x=[omega, area, coords["q2"], r])
+    g_t = deriv_time(f=f, times=times)
+
+    # oracle
+    o_omega = omega.detach().clone().requires_grad_(True)
+    o_area = area.detach().clone().requires_grad_(True)
+    o_q2 = coords["q2"].detach().clone().requires_grad_(True)
+    oseq = R.concat_pulses([(R.blackman_waveform(200, o_area), R.ramp_waveform(200, -4.0, 2.0), 0.3),
+                            (R.constant_waveform(100, o_omega), R.constant_waveform(100, 1.0), 0.0)])
+    ocoords = torch.stack([coords["q0"], coords["q1"], o_q2])
+    dists = R.pair_distances(ocoords)
+    o_r = dists[1]
+    o_r.retain_grad()
+    oterms = R.build_terms(oseq, ocoords, 0.2, u_pairs=R.C6_MOCK_DEVICE / torch.stack(dists) ** 6)
+    o_ts = R.evaluation_times(oseq.tot_duration, 0.2).requires_grad_(True)
+    ost = R.krylov_map_dense(oterms, R.all_ground_state(3), o_ts)
+    of = (ost.abs() ** 2 * zdiag[None, :, None]).sum(dim=(1, 2))
+    assert np.abs(f.detach().cpu().numpy() - of.detach().numpy()).max() < 1e-10
+    idx = int(torch.abs(o_ts.detach() - 0.150).argmin())
+    for v_idx, got in ((idx, g_mid), (len(of) - 1, g_end)):
+        v = torch.zeros(len(of), dtype=torch.float64)
+        v[v_idx] = 1.0
+        ref = torch.autograd.grad(of, [o_omega, o_area, o_q2, o_r], v, retain_graph=True)
+        for a, b in zip(got, ref):
+            assert np.abs(a.detach().cpu().numpy() - b.numpy()).max() < 1e-8 * max(1.0, float(b.abs().max()))
+    ref_t = torch.autograd.grad(of, o_ts, torch.ones_like(of), retain_graph=True)[0]
+    assert np.abs(g_t.detach().cpu().numpy() - ref_t.numpy()).max() < 1e-8 * float(ref_t.abs().max())
+
+
+def test_local_channel_sequence_and_batched_initial_states(cuda_device):
+    reg = pl.Register.rectangle(1, 3, spacing=7)
+    seq = pl.Sequence(reg, pl.MockDevice)
+    seq.declare_channel("g", "rydberg_global")
+    seq.declare_channel("l", "rydberg_local", initial_target="q1")
+    seq.add(pl.Pulse.ConstantPulse(120, 4.0, 1.0, 0.2), "g")
+    seq.add(pl.Pulse(pl.RampWaveform(80, 0.0, 6.0), pl.ConstantWaveform(80, -2.0), 0.5), "l")
+    sim = P.TorchEmulator.from_sequence(seq)
+    sim.set_initial_state(torch.eye(8, dtype=torch.complex128))  # gate-optimisation style: (dim, B=dim)
+    res = sim.run(solver=SolverType.KRYLOV_SE)
+    states = res.states.cpu()  # (n_t, dim, B)
+    # oracle with the same tables
+    ham = sim._hamiltonian
+    terms = R.HamTerms(3, ham._u_pairs_host, ham._amp_terms[0][0], ham._det_terms[0][0], ham.dt, ham.n_samples,
+                       [0, 1, 2], [0, 1, 2])
+    terms.extra_amp = [(ham._amp_terms[1][0], [1])]
+    terms.extra_det = [(ham._det_terms[1][0], [1])]
+    ref = R.krylov_map_dense(terms, torch.eye(8, dtype=torch.complex128), sim.evaluation_times)
+    assert (states - ref).abs().max() < 1e-10
+    # the propagator of a unitary evolution is unitary
+    u = states[-1]
+    assert (u.mH @ u - torch.eye(8)).abs().max() < 1e-11
+    assert isinstance(res[3].state, torch.Tensor) and res[3].state.shape == (8, 8)
+    assert sum(res.sample_final_state(100).values()) == 100
