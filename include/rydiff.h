@@ -90,7 +90,7 @@ typedef struct RydPlanInfo {
     int32_t degree;                  /* polynomial degree = matrix-free H applications per (sub-)exponential */
     int32_t n_stages;                /* exponentials in the run (KRYLOV_SE: one per tsave interval) */
     int32_t max_step_factors;        /* largest number of factor passes inside one tsave interval */
-    int32_t reserved;
+    int32_t flags;                   /* bit 0: some flip coefficient has a non-zero imaginary part */
     int64_t total_factors;           /* factor passes of one forward run = H applications per trajectory */
     size_t workspace_bytes;          /* device workspace needed by forward/backward for the flags given to rydiff_plan */
 } RydPlanInfo;

@@ -58,7 +58,7 @@ class RydPlanInfo(ctypes.Structure):
         ("degree", ctypes.c_int32),
         ("n_stages", ctypes.c_int32),
         ("max_step_factors", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("flags", ctypes.c_int32),
         ("total_factors", ctypes.c_int64),
         ("workspace_bytes", ctypes.c_size_t),
     ]

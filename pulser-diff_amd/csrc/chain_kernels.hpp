@@ -1,0 +1,183 @@
+// chain_kernels.hpp — LDS-tiled "chained two-layout" factor passes (included by rydiff.hip).
+//
+// One factor of the product-form propagator is  v_f = (gamma_f + beta_f H) v_{f-1},  H = D + sum_j flips_j.
+// A workgroup owns a TILE of 2^LT amplitudes in LDS/registers; flips on the tile's LT bits are local.  Two tile
+// layouts alternate between launches:
+//     layout A : tile = amplitude-index bits [0, LT)                       (one contiguous 2^LT run)
+//     layout B : tile = bits [0, 2LT-N) u [LT, N)                         (2^(N-LT) runs of 2^(2LT-N) amplitudes)
+// so that A u B covers all N bits (13 <= N <= 2 LT).  Kernel j (layout X_j)
+//     1. FINISHES factor j:   v_j = p_j + beta_j * flips_{X_j \ X_{j-1}} v_{j-1}      (p_j = partial from kernel j-1)
+//     2. STARTS  factor j+1:  p_{j+1} = (gamma_{j+1} + beta_{j+1} D) v_j + beta_{j+1} * flips_{X_j} v_j
+// and writes v_j (complete) and p_{j+1} (partial).  Every launch therefore reads two vectors and writes two, once,
+// fully coalesced, whatever N is — no partner-tile loads, no dependence on workgroup->XCD placement — and one matrix-
+// free application of H costs exactly one launch.
+//
+// Per thread: R = 2^(LT-LGT) amplitudes i = r*NT + tid, so the top LT-LGT tile bits are REGISTER bits (flips are
+// register renaming) and only the low LGT tile bits go through LDS (conflict-free ds_read_b128: consecutive lanes
+// read consecutive 16-byte slots of a permuted 1 KiB span).
+#pragma once
+
+constexpr int kTileBits = 12;
+
+struct ChainArgs {
+    const double2* u;      // complete v_{j-1}
+    const double2* p;      // partial of factor j (unused when !has_p)
+    double2* v_out;        // complete v_j (written when write_v)
+    double2* q_out;        // partial of factor j+1 (written when has_q)
+    const double* udiag;
+    const double* coef_fin;  // coefficient record of factor j     (trajectory 0)
+    const double* coef_sta;  // coefficient record of factor j+1
+    long coef_bstride;
+    double fb_r, fb_i;                 // beta_j
+    double sg_r, sg_i, sb_r, sb_i;     // gamma_{j+1}, beta_{j+1}
+    int lo, hs, hb;                    // layout: tile bits [0,lo) -> index bits [0,lo); tile bits [lo,LT) -> index bits [hs,hs+hb)
+    uint32_t dim;
+    int has_p, has_q, write_v;
+    int ga, gd;
+    uint32_t fin_mask[kMaxGroups];     // per flip group: TILE-bit mask handled by the finish stage
+    uint32_t sta_mask[kMaxGroups];     // per flip group: TILE-bit mask handled by the start stage
+    uint32_t dmask[kMaxGroups];        // detuning groups: amplitude-INDEX masks
+    int dcnt[kMaxGroups];
+};
+
+// partner sums over the tile bits in `mask`:  ts[r] = sum of partners, ds[r] = sum(+partner if own bit set else -partner)
+template <int LT, int LGT, bool CPLX>
+__device__ __forceinline__ void partner_sums(const double2* __restrict__ tile, const double2 (&reg)[1 << (LT - LGT)],
+                                             uint32_t mask, unsigned tid, double2 (&ts)[1 << (LT - LGT)],
+                                             double2 (&ds)[1 << (LT - LGT)]) {
+    constexpr int NT = 1 << LGT, R = 1 << (LT - LGT);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        ts[r] = make_double2(0.0, 0.0);
+        ds[r] = make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int b = 0; b < LT; ++b) {
+        if (mask >> b & 1u) {  // wave-uniform
+            if (b < LGT) {
+                const double sgn = (tid >> b & 1u) ? 1.0 : -1.0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const double2 q = tile[(unsigned(r) * NT + tid) ^ (1u << b)];
+                    ts[r].x += q.x;
+                    ts[r].y += q.y;
+                    if (CPLX) {
+                        ds[r].x = fma(sgn, q.x, ds[r].x);
+                        ds[r].y = fma(sgn, q.y, ds[r].y);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const double2 q = reg[r ^ (1 << (b - LGT))];
+                    ts[r].x += q.x;
+                    ts[r].y += q.y;
+                    if (CPLX) {
+                        if (r >> (b - LGT) & 1) {
+                            ds[r].x += q.x;
+                            ds[r].y += q.y;
+                        } else {
+                            ds[r].x -= q.x;
+                            ds[r].y -= q.y;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int LT, int LGT, bool CPLX>
+__global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
+    constexpr int NT = 1 << LGT, R = 1 << (LT - LGT);
+    extern __shared__ __attribute__((aligned(16))) double2 tile[];
+    const unsigned tid = threadIdx.x;
+    const unsigned t = blockIdx.x;
+    const size_t boff = size_t(blockIdx.y) * a.dim;
+    const unsigned lomask = (1u << a.lo) - 1u;
+    const int midlow = a.hs - a.lo;
+    const unsigned xbase = ((t & ((1u << midlow) - 1u)) << a.lo) | ((t >> midlow) << (a.hs + a.hb));
+
+    double2 uu[R], acc[R];
+    unsigned xg[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned i = unsigned(r) * NT + tid;
+        xg[r] = xbase | (i & lomask) | ((i >> a.lo) << a.hs);
+        uu[r] = a.u[boff + xg[r]];
+    }
+    if (a.has_p) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = a.p[boff + xg[r]];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) tile[unsigned(r) * NT + tid] = uu[r];
+    __syncthreads();
+
+    if (a.has_p) {
+        const double* __restrict__ cf = a.coef_fin + blockIdx.y * a.coef_bstride;
+        for (int g = 0; g < a.ga; ++g) {
+            const uint32_t mask = a.fin_mask[g];
+            if (!mask) continue;
+            double2 ts[R], ds[R];
+            partner_sums<LT, LGT, CPLX>(tile, uu, mask, tid, ts, ds);
+            const double cr = cf[g], ci = cf[a.ga + g];
+            // c*s1 + conj(c)*s0 = cr*(s1+s0) + i*ci*(s1-s0);  k1 = beta*cr, k2 = beta*i*ci
+            const double k1r = a.fb_r * cr, k1i = a.fb_i * cr;
+            const double k2r = -a.fb_i * ci, k2i = a.fb_r * ci;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                acc[r].x += k1r * ts[r].x - k1i * ts[r].y;
+                acc[r].y += k1r * ts[r].y + k1i * ts[r].x;
+                if (CPLX) {
+                    acc[r].x += k2r * ds[r].x - k2i * ds[r].y;
+                    acc[r].y += k2r * ds[r].y + k2i * ds[r].x;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = uu[r];
+    }
+    if (a.write_v) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) a.v_out[boff + xg[r]] = acc[r];
+    }
+    if (!a.has_q) return;
+
+    __syncthreads();  // all partner reads of u are done
+#pragma unroll
+    for (int r = 0; r < R; ++r) tile[unsigned(r) * NT + tid] = acc[r];
+    __syncthreads();
+
+    const double* __restrict__ cf = a.coef_sta + blockIdx.y * a.coef_bstride;
+    double2 q[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        double d = a.udiag[xg[r]];
+        for (int g = 0; g < a.gd; ++g) d += cf[2 * a.ga + g] * double(a.dcnt[g] - __popc(xg[r] & a.dmask[g]));
+        const double dr = a.sg_r + a.sb_r * d, di = a.sg_i + a.sb_i * d;
+        q[r].x = dr * acc[r].x - di * acc[r].y;
+        q[r].y = dr * acc[r].y + di * acc[r].x;
+    }
+    for (int g = 0; g < a.ga; ++g) {
+        const uint32_t mask = a.sta_mask[g];
+        if (!mask) continue;
+        double2 ts[R], ds[R];
+        partner_sums<LT, LGT, CPLX>(tile, acc, mask, tid, ts, ds);
+        const double cr = cf[g], ci = cf[a.ga + g];
+        const double k1r = a.sb_r * cr, k1i = a.sb_i * cr;
+        const double k2r = -a.sb_i * ci, k2i = a.sb_r * ci;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            q[r].x += k1r * ts[r].x - k1i * ts[r].y;
+            q[r].y += k1r * ts[r].y + k1i * ts[r].x;
+            if (CPLX) {
+                q[r].x += k2r * ds[r].x - k2i * ds[r].y;
+                q[r].y += k2r * ds[r].y + k2i * ds[r].x;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) a.q_out[boff + xg[r]] = q[r];
+}

@@ -168,7 +168,7 @@ __global__ void k_table_stats(unsigned long long* __restrict__ stats, StatsArgs 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (i < a.n_samples) {
-        double flip = 0.0, dpos = 0.0, dneg = 0.0;
+        double flip = 0.0, dpos = 0.0, dneg = 0.0, imabs = 0.0;
         for (int g = 0; g < a.ga; ++g) {
             double re = 0.0, im = 0.0;
             for (int k = 0; k < a.Ka; ++k)
@@ -178,6 +178,7 @@ __global__ void k_table_stats(unsigned long long* __restrict__ stats, StatsArgs 
                     im += v.y;
                 }
             flip += sqrt(re * re + im * im) * a.acnt[g];
+            imabs += fabs(im);
         }
         for (int g = 0; g < a.gd; ++g) {
             double d = 0.0;
@@ -189,6 +190,7 @@ __global__ void k_table_stats(unsigned long long* __restrict__ stats, StatsArgs 
         atomicMax(stats + 0, (unsigned long long)__double_as_longlong(flip));
         atomicMax(stats + 1, (unsigned long long)__double_as_longlong(dpos));
         atomicMax(stats + 2, (unsigned long long)__double_as_longlong(dneg));
+        atomicMax(stats + 4, (unsigned long long)__double_as_longlong(imabs));
     }
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         double s = 0.0;
@@ -531,6 +533,8 @@ __global__ void k_scatter_grads(ScatterArgs a) {
     }
 }
 
+#include "chain_kernels.hpp"
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -542,6 +546,7 @@ struct Runtime {
     double sigma = 0.0, width = 1.0, rho_design = 1.0;
     int64_t total_factors = 0;
     int max_step_factors = 0;
+    int flags = 0;
     GroupArgs garg{};
 };
 
@@ -597,7 +602,7 @@ int finish_runtime(Runtime& rt, double lo, double hi) {
     return RYDIFF_OK;
 }
 
-int run_stats(const RydProblem* p, const Plan& pl, void* scratch, hipStream_t stream, double& lo, double& hi) {
+int run_stats(const RydProblem* p, const Plan& pl, void* scratch, hipStream_t stream, double& lo, double& hi, int& flags) {
     StatsArgs sa{};
     sa.amp = static_cast<const double2*>(p->amp_tables);
     sa.det = p->det_tables;
@@ -622,7 +627,7 @@ int run_stats(const RydProblem* p, const Plan& pl, void* scratch, hipStream_t st
     dim3 grid((ns + 127) / 128, pl.Bc);
     hipLaunchKernelGGL(k_table_stats, grid, dim3(128), 0, stream, static_cast<unsigned long long*>(scratch), sa);
     LAUNCH_CHECK();
-    double host[4] = {0, 0, 0, 0};
+    double host[5] = {0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(host, scratch, sizeof(host), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     // interpolation weights: KRYLOV_SE uses convex combinations (sum |w| = 1); keep the general bound
@@ -634,6 +639,7 @@ int run_stats(const RydProblem* p, const Plan& pl, void* scratch, hipStream_t st
     }
     hi = host[3] + wsum * (host[1] + host[0]);
     lo = -wsum * (host[2] + host[0]);
+    flags = (host[4] != 0.0) ? 1 : 0;  // bit 0: some flip coefficient has a non-zero imaginary part (phase != 0)
     return RYDIFF_OK;
 }
 
@@ -644,7 +650,7 @@ void fill_info(const Runtime& rt, double lo, double hi, size_t ws, RydPlanInfo* 
     info->degree = rt.poly.degree;
     info->n_stages = int(rt.pl.stages.size());
     info->max_step_factors = rt.max_step_factors;
-    info->reserved = 0;
+    info->flags = rt.flags;
     info->total_factors = rt.total_factors;
     info->workspace_bytes = ws;
 }
@@ -659,9 +665,10 @@ int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_
     if (info) {
         lo = info->spectral_lo;
         hi = info->spectral_hi;
+        rt.flags = info->flags;
     } else {
         if (workspace_bytes < RYDIFF_PLAN_SCRATCH_BYTES) return fail(RYDIFF_EWORKSPACE, "workspace too small");
-        int rc = run_stats(p, rt.pl, workspace, stream, lo, hi);
+        int rc = run_stats(p, rt.pl, workspace, stream, lo, hi, rt.flags);
         if (rc) return rc;
     }
     int rc = finish_runtime(rt, lo, hi);
@@ -770,6 +777,156 @@ int launch_factor(const Runtime& rt, char* ws, const double2* xin, double2* xout
     return RYDIFF_OK;
 }
 
+// ---- chained two-layout passes (chain_kernels.hpp) ---------------------------------------------------------------
+struct LayoutDesc {
+    int lo, hs, hb;
+    uint32_t bits;  // amplitude-index bits covered by the tile
+};
+
+LayoutDesc chain_layout(int N, int which) {
+    LayoutDesc d{};
+    if (which == 0) {  // A
+        d.lo = kTileBits;
+        d.hs = kTileBits;
+        d.hb = 0;
+        d.bits = (1u << kTileBits) - 1u;
+    } else {  // B
+        d.hb = N - kTileBits;
+        d.hs = kTileBits;
+        d.lo = 2 * kTileBits - N;
+        d.bits = ((1u << d.lo) - 1u) | (((1u << d.hb) - 1u) << kTileBits);
+    }
+    return d;
+}
+
+uint32_t to_tile_mask(const LayoutDesc& d, uint32_t index_mask) {
+    uint32_t m = 0;
+    for (int b = 0; b < kTileBits; ++b) {
+        const int gb = b < d.lo ? b : d.hs + (b - d.lo);
+        if (index_mask >> gb & 1u) m |= 1u << b;
+    }
+    return m;
+}
+
+bool chain_enabled(const Runtime& rt) {
+    const int N = rt.pl.N;
+    if (g_kernel_variant == 1) return false;
+    return N > kTileBits && N <= 2 * kTileBits;
+}
+
+struct ChainStep {
+    // kernel j finishes factor `fin` (if has_p) and starts factor `sta` (if has_q)
+    const double2* u;
+    const double2* p;
+    double2* v_out;
+    double2* q_out;
+    int fin_stage, sta_stage;
+    FactorScalars fin, sta;
+    int has_p, has_q, write_v;
+    int layout, prev_layout;
+};
+
+template <int LGT, bool CPLX>
+int launch_chain_t(const ChainArgs& ca, unsigned tiles, int B, hipStream_t stream) {
+    static bool attr_set = false;
+    const size_t lds = (size_t(1) << kTileBits) * sizeof(double2);
+    auto kern = k_chain<kTileBits, LGT, CPLX>;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles, B), dim3(1 << LGT), lds, stream, ca);
+    LAUNCH_CHECK();
+    return RYDIFF_OK;
+}
+
+int g_chain_lgt = 9;  // log2(threads per tile workgroup): 512 threads, 8 amplitudes per thread
+
+int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, hipStream_t stream) {
+    const Plan& pl = rt.pl;
+    const LayoutDesc X = chain_layout(pl.N, cs.layout);
+    ChainArgs ca{};
+    ca.u = cs.u;
+    ca.p = cs.p;
+    ca.v_out = cs.v_out;
+    ca.q_out = cs.q_out;
+    ca.udiag = reinterpret_cast<const double*>(ws + pl.off_udiag);
+    const double* coef = reinterpret_cast<const double*>(ws + pl.off_coef);
+    ca.coef_fin = coef + size_t(std::max(cs.fin_stage, 0)) * pl.NC;
+    ca.coef_sta = coef + size_t(std::max(cs.sta_stage, 0)) * pl.NC;
+    ca.coef_bstride = pl.Bc > 1 ? long(pl.stages.size()) * pl.NC : 0;
+    ca.fb_r = cs.fin.br;
+    ca.fb_i = cs.fin.bi;
+    ca.sg_r = cs.sta.gr;
+    ca.sg_i = cs.sta.gi;
+    ca.sb_r = cs.sta.br;
+    ca.sb_i = cs.sta.bi;
+    ca.lo = X.lo;
+    ca.hs = X.hs;
+    ca.hb = X.hb;
+    ca.dim = uint32_t(pl.dim);
+    ca.has_p = cs.has_p;
+    ca.has_q = cs.has_q;
+    ca.write_v = cs.write_v;
+    ca.ga = pl.ga.n;
+    ca.gd = pl.gd.n;
+    const uint32_t prev_bits = cs.prev_layout >= 0 ? chain_layout(pl.N, cs.prev_layout).bits : 0u;
+    for (int g = 0; g < pl.ga.n; ++g) {
+        ca.fin_mask[g] = to_tile_mask(X, pl.ga.amp_index_mask[g] & ~prev_bits);
+        ca.sta_mask[g] = to_tile_mask(X, pl.ga.amp_index_mask[g]);
+    }
+    for (int g = 0; g < pl.gd.n; ++g) {
+        ca.dmask[g] = pl.gd.amp_index_mask[g];
+        ca.dcnt[g] = pl.gd.count[g];
+    }
+    const unsigned tiles = unsigned(pl.dim >> kTileBits);
+    const bool cplx = (rt.flags & 1) != 0;
+    switch (g_chain_lgt) {
+        case 8: return cplx ? launch_chain_t<8, true>(ca, tiles, pl.B, stream) : launch_chain_t<8, false>(ca, tiles, pl.B, stream);
+        case 10: return cplx ? launch_chain_t<10, true>(ca, tiles, pl.B, stream) : launch_chain_t<10, false>(ca, tiles, pl.B, stream);
+        default: return cplx ? launch_chain_t<9, true>(ca, tiles, pl.B, stream) : launch_chain_t<9, false>(ca, tiles, pl.B, stream);
+    }
+}
+
+// Run `items` (factors, in order) as a chain starting from the complete vector `start`.
+//   dst(i)   : where the complete output of factor i (0-based) goes, or nullptr to skip storing it (only legal for the last)
+//   on_done(i, ptr): called after the launch that completed factor i
+// skip_last_finish: do not finish the last factor (its output is not needed) — used by the backward recompute.
+template <class DstFn, class DoneFn>
+int run_chain(const Runtime& rt, char* ws, const std::vector<ChainItem>& items, const double2* start, DstFn dst, DoneFn on_done,
+              bool skip_last_finish, hipStream_t stream) {
+    const Plan& pl = rt.pl;
+    double2* pp[2] = {reinterpret_cast<double2*>(ws + pl.off_pp0), reinterpret_cast<double2*>(ws + pl.off_pp1)};
+    const int F = int(items.size());
+    const int n_launch = skip_last_finish ? F : F + 1;
+    const double2* cur = start;
+    for (int j = 0; j < n_launch; ++j) {
+        ChainStep cs{};
+        cs.layout = j & 1;
+        cs.prev_layout = j > 0 ? ((j - 1) & 1) : -1;
+        cs.u = cur;
+        cs.has_p = j >= 1;
+        cs.has_q = (j < F) && !(skip_last_finish && j == F - 1);
+        cs.p = cs.has_p ? pp[(j - 1) & 1] : nullptr;
+        cs.q_out = cs.has_q ? pp[j & 1] : nullptr;
+        cs.write_v = cs.has_p;
+        cs.v_out = cs.has_p ? dst(j - 1) : nullptr;
+        cs.fin_stage = cs.has_p ? items[j - 1].stage : -1;
+        cs.sta_stage = cs.has_q ? items[j].stage : -1;
+        if (cs.has_p) cs.fin = items[j - 1].s;
+        if (cs.has_q) cs.sta = items[j].s;
+        if (cs.has_p && !cs.v_out) return fail(RYDIFF_EINVAL, "internal: chain destination missing");
+        int rc = launch_chain(rt, ws, cs, stream);
+        if (rc) return rc;
+        if (cs.has_p) {
+            cur = cs.v_out;
+            rc = on_done(j - 1, cs.v_out);
+            if (rc) return rc;
+        }
+    }
+    return RYDIFF_OK;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -810,7 +967,7 @@ int rydiff_plan(const RydProblem* p, int need_tape, int need_backward, void* scr
     std::string err;
     if (!build_plan(p, rt.pl, err)) return fail(err.find("not implemented") != std::string::npos ? RYDIFF_ENOTIMPL : RYDIFF_EINVAL, err);
     double lo, hi;
-    int rc = run_stats(p, rt.pl, scratch, stream, lo, hi);
+    int rc = run_stats(p, rt.pl, scratch, stream, lo, hi, rt.flags);
     if (rc) return rc;
     rc = finish_runtime(rt, lo, hi);
     if (rc) return rc;
@@ -846,6 +1003,34 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
         LAUNCH_CHECK();
     }
     std::vector<ChainItem> chain;
+    if (chain_enabled(rt)) {
+        // one chain over the whole run: factor i of step k; complete outputs at step ends go to the tape
+        std::vector<ChainItem> all;
+        std::vector<int> step_of_end;  // for factor i: k+1 if it ends step k, else 0
+        for (int k = 0; k < pl.T; ++k) {
+            build_step_chain(rt, k, chain);
+            for (size_t i = 0; i < chain.size(); ++i) {
+                all.push_back(chain[i]);
+                step_of_end.push_back(i + 1 == chain.size() ? k + 1 : 0);
+            }
+        }
+        int flip = 0;
+        auto dst = [&](int i) -> double2* {
+            if (step_of_end[i] && tape) return tape + size_t(step_of_end[i]) * sv;
+            flip ^= 1;
+            return buf[flip];
+        };
+        auto done = [&](int i, const double2* v) -> int {
+            if (want_exp && step_of_end[i]) {
+                hipLaunchKernelGGL(k_expect_diag, dim3(red_blocks, pl.B), dim3(256), 0, stream, v, obs, expect_out, pl.n_obs, pl.T + 1, step_of_end[i], pl.B, uint32_t(pl.dim));
+                LAUNCH_CHECK();
+            }
+            return RYDIFF_OK;
+        };
+        rc = run_chain(rt, ws, all, cur, dst, done, false, stream);
+        if (rc) return rc;
+        return RYDIFF_OK;
+    }
     int pp = 0;
     for (int k = 0; k < pl.T; ++k) {
         build_step_chain(rt, k, chain);
@@ -918,11 +1103,19 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
         // recompute the factor inputs x_0 .. x_{M-1}
         xs.assign(M + 1, nullptr);
         xs[0] = tape + size_t(k) * sv;
-        for (int i = 1; i < M; ++i) {
-            double2* dst = chainbuf + size_t(i - 1) * sv;
-            rc = launch_factor(rt, ws, xs[i - 1], dst, chain[i - 1].stage, chain[i - 1].s, stream);
+        if (chain_enabled(rt) && M > 1) {
+            for (int i = 1; i < M; ++i) xs[i] = chainbuf + size_t(i - 1) * sv;
+            auto dst = [&](int i) -> double2* { return chainbuf + size_t(i) * sv; };
+            auto done = [&](int, const double2*) -> int { return RYDIFF_OK; };
+            rc = run_chain(rt, ws, chain, xs[0], dst, done, true, stream);
             if (rc) return rc;
-            xs[i] = dst;
+        } else {
+            for (int i = 1; i < M; ++i) {
+                double2* dst = chainbuf + size_t(i - 1) * sv;
+                rc = launch_factor(rt, ws, xs[i - 1], dst, chain[i - 1].stage, chain[i - 1].s, stream);
+                if (rc) return rc;
+                xs[i] = dst;
+            }
         }
         xs[M] = tape + size_t(k + 1) * sv;
         for (int i = M; i >= 1; --i) {
