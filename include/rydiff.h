@@ -144,7 +144,8 @@ int rydiff_design_polynomial(double rho, double tol, int max_degree, int* degree
                              double* p0_reim, double* max_err);
 
 /* Selects the kernel implementation: 0 = auto, 1 = direct (one amplitude per thread, global partner loads),
- * 2 = LDS-tiled chained passes.  Used by parity tests to A/B the kernels against each other. */
+ * 2 / 3 / 4 = LDS-tiled chained two-layout passes with 512 / 256 / 1024 threads per tile (13 <= N <= 24 only).
+ * Used by parity tests to A/B the kernels against each other and by the tuning scripts. */
 int rydiff_set_kernel_variant(int variant);
 
 const char* rydiff_last_error(void);

@@ -938,8 +938,10 @@ const char* rydiff_last_error(void) { return g_last_error.c_str(); }
 const char* rydiff_version(void) { return "rydiff 0.1 (gfx950)"; }
 
 int rydiff_set_kernel_variant(int variant) {
-    if (variant < 0 || variant > 2) return fail(RYDIFF_EINVAL, "kernel variant must be 0, 1 or 2");
+    // 0 auto | 1 direct | 2 chained tiles, 512 threads | 3 chained tiles, 256 threads | 4 chained tiles, 1024 threads
+    if (variant < 0 || variant > 4) return fail(RYDIFF_EINVAL, "kernel variant must be 0..4");
     g_kernel_variant = variant;
+    g_chain_lgt = variant == 3 ? 8 : (variant == 4 ? 10 : 9);
     return RYDIFF_OK;
 }
 

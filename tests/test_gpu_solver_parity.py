@@ -174,3 +174,59 @@ def test_twelve_qubit_chain_against_matrix_free_oracle(cuda_device):
     ref = R.krylov_map_matrix_free(terms, psi0.numpy(), tsave.numpy(), save_all=False, tol=1e-14)
     states, _, spec = _native_run(terms, tsave, psi0.T.contiguous(), cuda_device)
     assert rel_err(states[-1].cpu().numpy().T, ref[-1]) < STATE_RTOL
+
+
+# ---- LDS-tiled chained kernels (N >= 13) ---------------------------------------------------------------------------
+def _run_variant(variant, terms, tsave, psi_bd, device, obs, grads=True, batch_tables=1):
+    from pulser_diff_amd import _native
+    from pulser_diff_amd.solver import SolverType, evolve
+
+    _native.set_kernel_variant(variant)
+    try:
+        amp, det, u, spec = to_native(terms, device, SolverType.KRYLOV_SE, batch_tables=batch_tables)
+        if grads:
+            amp.requires_grad_(True)
+            det.requires_grad_(True)
+            u.requires_grad_(True)
+        states, expect = evolve(amp, det, u, tsave, psi_bd, spec, obs)
+        out = {"states": states.detach(), "expect": expect.detach()}
+        if grads:
+            w = torch.linspace(0.5, 1.5, expect.shape[1], dtype=torch.float64, device=device)
+            (expect[0] * w[:, None]).sum().backward()
+            out.update(amp=amp.grad.clone(), det=det.grad.clone(), u=u.grad.clone())
+        torch.cuda.synchronize()
+        return out
+    finally:
+        _native.set_kernel_variant(0)
+
+
+@pytest.mark.parametrize("n_qubits,local,variant", [(13, True, 2), (14, False, 3), (16, True, 4), (17, True, 2), (20, False, 2)])
+def test_chained_tile_kernels_match_direct_kernels(cuda_device, n_qubits, local, variant):
+    """A/B on the GPU: the chained two-layout LDS kernels against the one-amplitude-per-thread kernels (which are
+    themselves pinned to the oracle above) — states, expectation values and gradients, complex coefficients."""
+    terms = random_terms(n_qubits, 17, 0.002, seed=200 + n_qubits, local=local)
+    tsave = torch.linspace(0, 0.03, 7, dtype=torch.float64)
+    gen = torch.Generator().manual_seed(n_qubits)
+    psi = torch.randn(1, 2**n_qubits, generator=gen, dtype=torch.complex128)
+    psi = (psi / psi.norm()).to(cuda_device)
+    obs = R.total_magnetization_diag(n_qubits)[None].to(cuda_device)
+    ref = _run_variant(1, terms, tsave, psi, cuda_device, obs)
+    got = _run_variant(variant, terms, tsave, psi, cuda_device, obs)
+    assert rel_err(got["states"].cpu().numpy(), ref["states"].cpu().numpy()) < 1e-12
+    assert np.abs((got["expect"] - ref["expect"]).cpu().numpy()).max() < 1e-10
+    for key in ("amp", "det", "u"):
+        assert rel_err(got[key].cpu().numpy(), ref[key].cpu().numpy()) < 1e-10, key
+
+
+def test_chained_tile_kernels_against_matrix_free_oracle(cuda_device):
+    """N = 14 (two tile layouts in play) directly against the CPU oracle, batch of 2 trajectories with their own tables."""
+    n = 14
+    terms = random_terms(n, 13, 0.002, seed=77, local=True)
+    tsave = torch.linspace(0, 0.022, 6, dtype=torch.float64)
+    psi0 = R.all_ground_state(n)
+    ref = R.krylov_map_matrix_free(terms, psi0.numpy(), tsave.numpy(), save_all=True, tol=1e-14)
+    got = _run_variant(2, terms, tsave, psi0.T.contiguous().to(cuda_device).repeat(2, 1), cuda_device, None, grads=False,
+                       batch_tables=2)
+    st = got["states"].cpu().numpy()  # (n_t, B, dim)
+    assert rel_err(st[:, 0, :], ref[:, :, 0]) < STATE_RTOL
+    assert rel_err(st[:, 1, :], ref[:, :, 0]) < STATE_RTOL
