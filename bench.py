@@ -71,6 +71,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU (default: 1; c4: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant (rydiff_set_kernel_variant); 0 = auto")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -86,7 +87,10 @@ def main() -> None:
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
+    from pulser_diff_amd import _native
     from pulser_diff_amd.solver import ProblemSpec, SolverType, evolve
+
+    _native.set_kernel_variant(args.variant)
 
     n_qubits, coords, segs, seg_len = build_workload(args.workload, device, 0)
     batch = args.batch or (32 if args.workload == "c4" else 1)

@@ -38,7 +38,31 @@ struct ChainArgs {
     uint32_t sta_mask[kMaxGroups];     // per flip group: TILE-bit mask handled by the start stage
     uint32_t dmask[kMaxGroups];        // detuning groups: amplitude-INDEX masks
     int dcnt[kMaxGroups];
+    // backward (adjoint) mode only: u/p/v/q are cotangents, gamma/beta above are already conjugated
+    const double2* x_fin;   // input of the factor being finished (own elements only)
+    const double2* x_sta;   // input of the factor being started
+    double* ge_fin;         // gradient record of the finished factor's exponential (trajectory 0, replica 0)
+    double* ge_sta;
+    long ge_bstride, ge_rstride;
+    double cb_fin_r, cb_fin_i, cb_sta_r, cb_sta_i;  // un-conjugated beta of the two factors (contraction weights)
+    double* wtot;           // optional U_ij-gradient accumulator [dim]
 };
+
+// sum over the workgroup, then one atomic into the replica slot
+template <int NT>
+__device__ __forceinline__ void wg_atomic_add(double v, double* dst, double* red /* >= NT/64 doubles */) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) s2 += red[w];
+        unsafeAtomicAdd(dst, s2);
+    }
+}
 
 // partner sums over the tile bits in `mask`:  ts[r] = sum of partners, ds[r] = sum(+partner if own bit set else -partner)
 template <int LT, int LGT, bool CPLX>
@@ -87,10 +111,11 @@ __device__ __forceinline__ void partner_sums(const double2* __restrict__ tile, c
     }
 }
 
-template <int LT, int LGT, bool CPLX>
+template <int LT, int LGT, bool CPLX, bool BWD>
 __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     constexpr int NT = 1 << LGT, R = 1 << (LT - LGT);
     extern __shared__ __attribute__((aligned(16))) double2 tile[];
+    double* red = reinterpret_cast<double*>(tile + (size_t(1) << LT));  // NT/64 doubles behind the tile (BWD only)
     const unsigned tid = threadIdx.x;
     const unsigned t = blockIdx.x;
     const size_t boff = size_t(blockIdx.y) * a.dim;
@@ -110,9 +135,26 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = a.p[boff + xg[r]];
     }
+    double dg[R];  // static interaction diagonal, fetched early so its latency hides behind the finish stage
+    if (a.has_q) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) dg[r] = a.udiag[xg[r]];
+    }
+    double2 xf[R], xs[R];
+    if (BWD && a.has_p) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) xf[r] = a.x_fin[boff + xg[r]];
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) tile[unsigned(r) * NT + tid] = uu[r];
     __syncthreads();
+    double* ge_fin = nullptr;
+    double* ge_sta = nullptr;
+    if (BWD) {
+        const long goff = blockIdx.y * a.ge_bstride + (blockIdx.x % kGradReplicas) * a.ge_rstride;
+        ge_fin = a.ge_fin + goff;
+        ge_sta = a.ge_sta + goff;
+    }
 
     if (a.has_p) {
         const double* __restrict__ cf = a.coef_fin + blockIdx.y * a.coef_bstride;
@@ -120,7 +162,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
             const uint32_t mask = a.fin_mask[g];
             if (!mask) continue;
             double2 ts[R], ds[R];
-            partner_sums<LT, LGT, CPLX>(tile, uu, mask, tid, ts, ds);
+            partner_sums<LT, LGT, CPLX || BWD>(tile, uu, mask, tid, ts, ds);
             const double cr = cf[g], ci = cf[a.ga + g];
             // c*s1 + conj(c)*s0 = cr*(s1+s0) + i*ci*(s1-s0);  k1 = beta*cr, k2 = beta*i*ci
             const double k1r = a.fb_r * cr, k1i = a.fb_i * cr;
@@ -134,10 +176,27 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
                     acc[r].y += k2r * ds[r].y + k2i * ds[r].x;
                 }
             }
+            if (BWD) {
+                // <F mu, x> with F Hermitian: z1 = sum conj(ts) x, z2 = sum conj(ds) x; dL/dRe c = Re(beta z1), dL/dIm c = Im(beta z2)
+                double z1r = 0.0, z1i = 0.0, z2r = 0.0, z2i = 0.0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    z1r += ts[r].x * xf[r].x + ts[r].y * xf[r].y;
+                    z1i += ts[r].x * xf[r].y - ts[r].y * xf[r].x;
+                    z2r += ds[r].x * xf[r].x + ds[r].y * xf[r].y;
+                    z2i += ds[r].x * xf[r].y - ds[r].y * xf[r].x;
+                }
+                wg_atomic_add<NT>(a.cb_fin_r * z1r - a.cb_fin_i * z1i, ge_fin + g, red);
+                wg_atomic_add<NT>(a.cb_fin_r * z2i + a.cb_fin_i * z2r, ge_fin + a.ga + g, red);
+            }
         }
     } else {
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = uu[r];
+    }
+    if (BWD && a.has_q) {  // issued here (not at the top) to stay inside the register budget of 1024-thread tiles
+#pragma unroll
+        for (int r = 0; r < R; ++r) xs[r] = a.x_sta[boff + xg[r]];
     }
     if (a.write_v) {
 #pragma unroll
@@ -151,10 +210,25 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     __syncthreads();
 
     const double* __restrict__ cf = a.coef_sta + blockIdx.y * a.coef_bstride;
+    double rr[R];  // Re(beta conj(mu) x): weight of d(x) in the gradient
+    if (BWD) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double pr = a.cb_sta_r * acc[r].x + a.cb_sta_i * acc[r].y, pi = a.cb_sta_i * acc[r].x - a.cb_sta_r * acc[r].y;
+            rr[r] = pr * xs[r].x - pi * xs[r].y;
+            if (a.wtot) unsafeAtomicAdd(a.wtot + xg[r], rr[r]);
+        }
+        for (int g = 0; g < a.gd; ++g) {
+            double sgd = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) sgd += rr[r] * double(a.dcnt[g] - __popc(xg[r] & a.dmask[g]));
+            wg_atomic_add<NT>(sgd, ge_sta + 2 * a.ga + g, red);
+        }
+    }
     double2 q[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        double d = a.udiag[xg[r]];
+        double d = dg[r];
         for (int g = 0; g < a.gd; ++g) d += cf[2 * a.ga + g] * double(a.dcnt[g] - __popc(xg[r] & a.dmask[g]));
         const double dr = a.sg_r + a.sb_r * d, di = a.sg_i + a.sb_i * d;
         q[r].x = dr * acc[r].x - di * acc[r].y;
@@ -164,7 +238,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
         const uint32_t mask = a.sta_mask[g];
         if (!mask) continue;
         double2 ts[R], ds[R];
-        partner_sums<LT, LGT, CPLX>(tile, acc, mask, tid, ts, ds);
+        partner_sums<LT, LGT, CPLX || BWD>(tile, acc, mask, tid, ts, ds);
         const double cr = cf[g], ci = cf[a.ga + g];
         const double k1r = a.sb_r * cr, k1i = a.sb_i * cr;
         const double k2r = -a.sb_i * ci, k2i = a.sb_r * ci;
@@ -176,6 +250,18 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
                 q[r].x += k2r * ds[r].x - k2i * ds[r].y;
                 q[r].y += k2r * ds[r].y + k2i * ds[r].x;
             }
+        }
+        if (BWD) {
+            double z1r = 0.0, z1i = 0.0, z2r = 0.0, z2i = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                z1r += ts[r].x * xs[r].x + ts[r].y * xs[r].y;
+                z1i += ts[r].x * xs[r].y - ts[r].y * xs[r].x;
+                z2r += ds[r].x * xs[r].x + ds[r].y * xs[r].y;
+                z2i += ds[r].x * xs[r].y - ds[r].y * xs[r].x;
+            }
+            wg_atomic_add<NT>(a.cb_sta_r * z1r - a.cb_sta_i * z1i, ge_sta + g, red);
+            wg_atomic_add<NT>(a.cb_sta_r * z2i + a.cb_sta_i * z2r, ge_sta + a.ga + g, red);
         }
     }
 #pragma unroll

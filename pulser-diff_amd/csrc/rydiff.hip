@@ -824,13 +824,19 @@ struct ChainStep {
     FactorScalars fin, sta;
     int has_p, has_q, write_v;
     int layout, prev_layout;
+    // backward mode
+    bool bwd = false;
+    const double2* x_fin = nullptr;
+    const double2* x_sta = nullptr;
+    double cb_fin_r = 0, cb_fin_i = 0, cb_sta_r = 0, cb_sta_i = 0;
+    double* wtot = nullptr;
 };
 
-template <int LGT, bool CPLX>
+template <int LGT, bool CPLX, bool BWD>
 int launch_chain_t(const ChainArgs& ca, unsigned tiles, int B, hipStream_t stream) {
     static bool attr_set = false;
-    const size_t lds = (size_t(1) << kTileBits) * sizeof(double2);
-    auto kern = k_chain<kTileBits, LGT, CPLX>;
+    const size_t lds = (size_t(1) << kTileBits) * sizeof(double2) + (BWD ? 256 : 0);
+    auto kern = k_chain<kTileBits, LGT, CPLX, BWD>;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
         attr_set = true;
@@ -838,6 +844,12 @@ int launch_chain_t(const ChainArgs& ca, unsigned tiles, int B, hipStream_t strea
     hipLaunchKernelGGL(kern, dim3(tiles, B), dim3(1 << LGT), lds, stream, ca);
     LAUNCH_CHECK();
     return RYDIFF_OK;
+}
+
+template <int LGT>
+int launch_chain_l(const ChainArgs& ca, unsigned tiles, int B, bool cplx, bool bwd, hipStream_t stream) {
+    if (bwd) return launch_chain_t<LGT, true, true>(ca, tiles, B, stream);  // the adjoint always needs both partner sums
+    return cplx ? launch_chain_t<LGT, true, false>(ca, tiles, B, stream) : launch_chain_t<LGT, false, false>(ca, tiles, B, stream);
 }
 
 int g_chain_lgt = 9;  // log2(threads per tile workgroup): 512 threads, 8 amplitudes per thread
@@ -879,12 +891,27 @@ int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, hipStream_t s
         ca.dmask[g] = pl.gd.amp_index_mask[g];
         ca.dcnt[g] = pl.gd.count[g];
     }
+    if (cs.bwd) {
+        double* ge = reinterpret_cast<double*>(ws + pl.off_ge);
+        const long ge_rec = long(kGradReplicas) * (pl.NC + 1);
+        ca.x_fin = cs.x_fin;
+        ca.x_sta = cs.x_sta;
+        ca.ge_fin = ge + size_t(std::max(cs.fin_stage, 0)) * ge_rec;
+        ca.ge_sta = ge + size_t(std::max(cs.sta_stage, 0)) * ge_rec;
+        ca.ge_bstride = pl.Bc > 1 ? long(pl.stages.size()) * ge_rec : 0;
+        ca.ge_rstride = pl.NC + 1;
+        ca.cb_fin_r = cs.cb_fin_r;
+        ca.cb_fin_i = cs.cb_fin_i;
+        ca.cb_sta_r = cs.cb_sta_r;
+        ca.cb_sta_i = cs.cb_sta_i;
+        ca.wtot = cs.wtot;
+    }
     const unsigned tiles = unsigned(pl.dim >> kTileBits);
     const bool cplx = (rt.flags & 1) != 0;
     switch (g_chain_lgt) {
-        case 8: return cplx ? launch_chain_t<8, true>(ca, tiles, pl.B, stream) : launch_chain_t<8, false>(ca, tiles, pl.B, stream);
-        case 10: return cplx ? launch_chain_t<10, true>(ca, tiles, pl.B, stream) : launch_chain_t<10, false>(ca, tiles, pl.B, stream);
-        default: return cplx ? launch_chain_t<9, true>(ca, tiles, pl.B, stream) : launch_chain_t<9, false>(ca, tiles, pl.B, stream);
+        case 8: return launch_chain_l<8>(ca, tiles, pl.B, cplx, cs.bwd, stream);
+        case 10: return launch_chain_l<10>(ca, tiles, pl.B, cplx, cs.bwd, stream);
+        default: return launch_chain_l<9>(ca, tiles, pl.B, cplx, cs.bwd, stream);
     }
 }
 
@@ -922,6 +949,68 @@ int run_chain(const Runtime& rt, char* ws, const std::vector<ChainItem>& items, 
             cur = cs.v_out;
             rc = on_done(j - 1, cs.v_out);
             if (rc) return rc;
+        }
+    }
+    return RYDIFF_OK;
+}
+
+// Adjoint sweep of one tsave interval as a chain.  `items` are the interval's forward factors (in forward order),
+// xs[i] the input of factor i, `lam_in` the cotangent w.r.t. the interval's output; the cotangent w.r.t. its input ends
+// up in `lam_out`.  on_stage_end(stage, lam, x_out) is called with the complete cotangent at every exponential's output.
+template <class StageEndFn>
+int run_chain_bwd(const Runtime& rt, char* ws, const std::vector<ChainItem>& items, const std::vector<const double2*>& xs,
+                  const double2* lam_in, double2* lam_bufs[2], int& cl, double* wtot, StageEndFn on_stage_end, hipStream_t stream) {
+    const Plan& pl = rt.pl;
+    double2* pp[2] = {reinterpret_cast<double2*>(ws + pl.off_pp0), reinterpret_cast<double2*>(ws + pl.off_pp1)};
+    const int M = int(items.size());
+    const double2* cur = lam_in;
+    // adjoint factor index a = 0..M-1 corresponds to forward factor f = M-1-a
+    for (int j = 0; j <= M; ++j) {
+        ChainStep cs{};
+        cs.bwd = true;
+        cs.layout = j & 1;
+        cs.prev_layout = j > 0 ? ((j - 1) & 1) : -1;
+        cs.u = cur;
+        cs.has_p = j >= 1;
+        cs.has_q = j < M;
+        cs.p = cs.has_p ? pp[(j - 1) & 1] : nullptr;
+        cs.q_out = cs.has_q ? pp[j & 1] : nullptr;
+        cs.write_v = cs.has_p;
+        cs.wtot = wtot;
+        if (cs.has_p) {
+            const ChainItem& it = items[M - j];  // forward factor being finished (adjoint index j-1)
+            cs.fin_stage = it.stage;
+            cs.fin = {it.s.gr, -it.s.gi, it.s.br, -it.s.bi};
+            cs.cb_fin_r = it.s.br;
+            cs.cb_fin_i = it.s.bi;
+            cs.x_fin = xs[M - j];
+            cl ^= 1;
+            cs.v_out = lam_bufs[cl];
+            if (cs.v_out == cur) return fail(RYDIFF_EINVAL, "internal: cotangent ping-pong clash");
+        }
+        if (cs.has_q) {
+            const ChainItem& it = items[M - 1 - j];
+            cs.sta_stage = it.stage;
+            cs.sta = {it.s.gr, -it.s.gi, it.s.br, -it.s.bi};
+            cs.cb_sta_r = it.s.br;
+            cs.cb_sta_i = it.s.bi;
+            cs.x_sta = xs[M - 1 - j];
+            // the cotangent `cur` (complete after this kernel's finish stage, or lam_in for j = 0) sits at the output of
+            // forward factor M-1-j: report exponential boundaries for dL/dtau
+            const bool stage_end = (j == 0) || (items[M - j].stage != it.stage);
+            if (stage_end && j == 0) {
+                int rc = on_stage_end(it.stage, cur, xs[M]);
+                if (rc) return rc;
+            }
+        }
+        int rc = launch_chain(rt, ws, cs, stream);
+        if (rc) return rc;
+        if (cs.has_p) {
+            cur = cs.v_out;
+            if (cs.has_q && items[M - j].stage != items[M - 1 - j].stage) {
+                rc = on_stage_end(items[M - 1 - j].stage, cur, xs[M - j]);
+                if (rc) return rc;
+            }
         }
     }
     return RYDIFF_OK;
@@ -1120,6 +1209,27 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
             }
         }
         xs[M] = tape + size_t(k + 1) * sv;
+        auto dot_h = [&](int stage, const double2* g, const double2* xout) -> int {
+            if (!g_tsave) return RYDIFF_OK;
+            DotHArgs da{};
+            da.g = g;
+            da.x = xout;
+            da.udiag = udiag;
+            da.coef = coef + size_t(stage) * pl.NC;
+            da.coef_bstride = coef_bstride;
+            da.out = ge + size_t(stage) * ge_rec + pl.NC;
+            da.out_bstride = ge_bstride;
+            da.out_rstride = pl.NC + 1;
+            da.dim = uint32_t(pl.dim);
+            da.gr = rt.garg;
+            hipLaunchKernelGGL(k_dot_hx, grid, dim3(256), 0, stream, da);
+            LAUNCH_CHECK();
+            return RYDIFF_OK;
+        };
+        if (chain_enabled(rt)) {
+            rc = run_chain_bwd(rt, ws, chain, xs, lam[cl], lam, cl, wtot, dot_h, stream);
+            if (rc) return rc;
+        } else
         for (int i = M; i >= 1; --i) {
             const ChainItem& it = chain[i - 1];
             // dL/dtau of an exponential is taken at its output (end of its last factor)
