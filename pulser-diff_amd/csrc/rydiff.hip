@@ -908,7 +908,9 @@ int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, hipStream_t s
     }
     const unsigned tiles = unsigned(pl.dim >> kTileBits);
     const bool cplx = (rt.flags & 1) != 0;
-    switch (g_chain_lgt) {
+    // auto: 1024 threads per tile for the forward passes, 512 for the (register-hungrier) adjoint passes
+    const int lgt = g_kernel_variant == 0 ? (cs.bwd ? 9 : 10) : g_chain_lgt;
+    switch (lgt) {
         case 8: return launch_chain_l<8>(ca, tiles, pl.B, cplx, cs.bwd, stream);
         case 10: return launch_chain_l<10>(ca, tiles, pl.B, cplx, cs.bwd, stream);
         default: return launch_chain_l<9>(ca, tiles, pl.B, cplx, cs.bwd, stream);
