@@ -470,8 +470,8 @@ struct ScatterArgs {
     const int32_t* idx;     // [E][4]
     const double* w;        // [E][4]
     const double* dwdt;     // [E][4]
-    const int32_t* tinfo;   // [E][3] = tnode, t_hi, t_lo
-    const double* tscale;   // [E]
+    const int32_t* tinfo;   // [E][4] = tn0, tn1, t_hi, t_lo  (-1: not a tsave point)
+    const double* tscale;   // [E][3] = tau_scale, tnw0, tnw1
     const double2* amp;     // tables (for d coef / d t)
     const double* det;
     double2* g_amp;
@@ -525,11 +525,12 @@ __global__ void k_scatter_grads(ScatterArgs a) {
         }
     }
     if (a.g_tsave) {
-        const int tnode = a.tinfo[e * 3 + 0], thi = a.tinfo[e * 3 + 1], tlo = a.tinfo[e * 3 + 2];
-        const double gtau = rec[a.NC] * a.tscale[e];
-        unsafeAtomicAdd(a.g_tsave + tnode, dLdt);
-        unsafeAtomicAdd(a.g_tsave + thi, gtau);
-        unsafeAtomicAdd(a.g_tsave + tlo, -gtau);
+        const int tn0 = a.tinfo[e * 4 + 0], tn1 = a.tinfo[e * 4 + 1], thi = a.tinfo[e * 4 + 2], tlo = a.tinfo[e * 4 + 3];
+        const double gtau = rec[a.NC] * a.tscale[e * 3 + 0];
+        if (tn0 >= 0) unsafeAtomicAdd(a.g_tsave + tn0, dLdt * a.tscale[e * 3 + 1]);
+        if (tn1 >= 0) unsafeAtomicAdd(a.g_tsave + tn1, dLdt * a.tscale[e * 3 + 2]);
+        if (thi >= 0) unsafeAtomicAdd(a.g_tsave + thi, gtau);
+        if (tlo >= 0) unsafeAtomicAdd(a.g_tsave + tlo, -gtau);
     }
 }
 
@@ -1287,17 +1288,20 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
     if (g_tsave) HIP_TRY(hipMemsetAsync(g_tsave, 0, size_t(pl.T + 1) * 8, stream));
     if ((g_amp && pl.Ka) || (g_det && pl.Kd) || g_tsave) {
         // extra metadata (dwdt, tinfo, tscale) lives at the start of the chain region, which is free now
-        std::vector<double> dwdt(E * 4), tscale(E);
-        std::vector<int32_t> tinfo(E * 3);
+        std::vector<double> dwdt(E * 4), tscale(E * 3);
+        std::vector<int32_t> tinfo(E * 4);
         for (size_t e = 0; e < E; ++e) {
             for (int q = 0; q < 4; ++q) dwdt[e * 4 + q] = pl.stages[e].dwdt[q];
-            tinfo[e * 3] = pl.stages[e].tnode;
-            tinfo[e * 3 + 1] = pl.stages[e].t_hi;
-            tinfo[e * 3 + 2] = pl.stages[e].t_lo;
-            tscale[e] = pl.stages[e].tau_scale;
+            tinfo[e * 4] = pl.stages[e].tn[0];
+            tinfo[e * 4 + 1] = pl.stages[e].tn[1];
+            tinfo[e * 4 + 2] = pl.stages[e].t_hi;
+            tinfo[e * 4 + 3] = pl.stages[e].t_lo;
+            tscale[e * 3] = pl.stages[e].tau_scale;
+            tscale[e * 3 + 1] = pl.stages[e].tnw[0];
+            tscale[e * 3 + 2] = pl.stages[e].tnw[1];
         }
         char* m = ws + pl.off_meta2;
-        const size_t o1 = align_up(E * 4 * sizeof(double)), o2 = o1 + align_up(E * 3 * sizeof(int32_t));
+        const size_t o1 = align_up(E * 4 * sizeof(double)), o2 = o1 + align_up(E * 4 * sizeof(int32_t));
         HIP_TRY(hipMemcpyAsync(m, dwdt.data(), dwdt.size() * sizeof(double), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(m + o1, tinfo.data(), tinfo.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(m + o2, tscale.data(), tscale.size() * sizeof(double), hipMemcpyHostToDevice, stream));

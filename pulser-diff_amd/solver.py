@@ -65,8 +65,8 @@ def tolerance_from_options(options: dict[str, Any]) -> float:
         if key in options:
             return float(options[key])
     if "atol" in options or "rtol" in options:
-        # DP5-style tolerances: aim two orders below the requested local accuracy
-        return max(min(float(options.get("atol", 1e-8)), float(options.get("rtol", 1e-6))) * 1e-2, 1e-15)
+        # DP5-style local tolerances: aim two orders below the requested accuracy
+        return max(min(float(options.get("atol", 1e-8)), float(options.get("rtol", 1e-6))) * 1e-2, 1e-14)
     return 0.0
 
 

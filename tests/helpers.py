@@ -59,3 +59,35 @@ def rel_err(a, b) -> float:
     b = np.asarray(b)
     den = max(float(np.abs(b).max()), 1e-300)
     return float(np.abs(a - b).max() / den)
+
+
+def magnus_cf4_dense(terms, psi0, tsave, h_max=2.5e-3):
+    """Torch (differentiable) model of the native continuous-time scheme: cut every tsave interval at the sample grid
+    (H(t) is linear in t on each piece, hamiltonian.py:532-542), advance each piece with S = ceil(h/h_max) CF4 Magnus
+    sub-steps exp(-i h/2 H(t0+5h/6)) exp(-i h/2 H(t0+h/6)).  Used to check the native adjoint tightly; the accuracy
+    claim itself is checked against the DOP853 oracle (R.continuous_solution)."""
+    import math
+
+    dt, n = terms.dt, terms.n_samples
+    psi = psi0
+    out = [psi]
+    for k in range(len(tsave) - 1):
+        a, b = tsave[k], tsave[k + 1]
+        fa, fb = float(a), float(b)
+        pts = [a]
+        i = math.floor(fa / dt) + 1
+        while i <= n - 2 and i * dt < fb - 1e-13:
+            if i * dt > fa + 1e-13:
+                pts.append(torch.tensor(i * dt, dtype=torch.float64))
+            i += 1
+        pts.append(b)
+        for p0, p1 in zip(pts[:-1], pts[1:]):
+            hf = p1 - p0
+            S = max(1, math.ceil(float(hf) / h_max - 1e-9))
+            for sub in range(S):
+                for theta in (1.0 / 6.0, 5.0 / 6.0):
+                    mu = (sub + theta) / S
+                    h = R.dense_hamiltonian(terms, p0 + mu * hf)
+                    psi = torch.linalg.matrix_exp(-1j * h * (hf / (2.0 * S))) @ psi
+        out.append(psi)
+    return torch.stack(out)
