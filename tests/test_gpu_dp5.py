@@ -74,7 +74,8 @@ def test_continuous_solver_adjoint_matches_autograd_of_the_same_scheme(cuda_devi
     m_terms.extra_amp = [(c.clone().requires_grad_(True), tg) for c, tg in terms.extra_amp]
     m_terms.extra_det = [(c.clone().requires_grad_(True), tg) for c, tg in terms.extra_det]
     m_ts = tsave0.clone().requires_grad_(True)
-    m_states = magnus_cf4_dense(m_terms, psi0, m_ts)
+    h_max = 2.5e-3 * (1e-9 / 1e-10) ** 0.25  # the native default: tol 1e-9 (csrc/plan.hpp)
+    m_states = magnus_cf4_dense(m_terms, psi0, m_ts, h_max=h_max)
     m_loss = ((m_states.abs() ** 2 * zdiag[None, :, None]).sum(dim=(1, 2)) * w).sum()
     m_loss.backward()
     # native
