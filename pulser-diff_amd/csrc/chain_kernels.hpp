@@ -24,7 +24,8 @@ struct ChainArgs {
     const double2* p;      // partial of factor j (unused when !has_p)
     double2* v_out;        // complete v_j (written when write_v)
     double2* q_out;        // partial of factor j+1 (written when has_q)
-    const double* udiag;
+    const double* utt;       // split interaction diagonal: U(x) = utt[i] + vr[t][LT] + sum_{tile bits a with n_a = 1} vr[t][a]
+    const double* vr;        // [tiles][16]
     const double* coef_fin;  // coefficient record of factor j     (trajectory 0)
     const double* coef_sta;  // coefficient record of factor j+1
     long coef_bstride;
@@ -46,6 +47,11 @@ struct ChainArgs {
     long ge_bstride, ge_rstride;
     double cb_fin_r, cb_fin_i, cb_sta_r, cb_sta_i;  // un-conjugated beta of the two factors (contraction weights)
     double* wtot;           // optional U_ij-gradient accumulator [dim]
+    // fused expectation values of the COMPLETE vector produced by the finish stage (forward mode, step ends)
+    const double* obs;      // [n_obs][dim] or nullptr
+    double* expect_slot;    // &expect_out[0][k][0]
+    int n_obs;
+    long exp_ostride;       // n_tsave * B
 };
 
 // sum over the workgroup, then one atomic into the replica slot
@@ -135,10 +141,10 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = a.p[boff + xg[r]];
     }
-    double dg[R];  // static interaction diagonal, fetched early so its latency hides behind the finish stage
+    double dg[R];  // tile-local part of the interaction diagonal (32 KiB table shared by all tiles: L2-resident)
     if (a.has_q) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) dg[r] = a.udiag[xg[r]];
+        for (int r = 0; r < R; ++r) dg[r] = a.utt[unsigned(r) * NT + tid];
     }
     double2 xf[R], xs[R];
     if (BWD && a.has_p) {
@@ -202,6 +208,14 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
 #pragma unroll
         for (int r = 0; r < R; ++r) a.v_out[boff + xg[r]] = acc[r];
     }
+    if (!BWD && a.obs) {  // <v|O|v> for diagonal observables, straight from the registers that hold v
+        for (int o = 0; o < a.n_obs; ++o) {
+            double e = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) e += a.obs[size_t(o) * a.dim + xg[r]] * (acc[r].x * acc[r].x + acc[r].y * acc[r].y);
+            wg_atomic_add<NT>(e, a.expect_slot + o * a.exp_ostride + blockIdx.y, red);
+        }
+    }
     if (!a.has_q) return;
 
     __syncthreads();  // all partner reads of u are done
@@ -210,6 +224,15 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     __syncthreads();
 
     const double* __restrict__ cf = a.coef_sta + blockIdx.y * a.coef_bstride;
+    // interaction diagonal: remote part of this tile + cross terms of the tile bits that are in |r> (n = 1 - bit)
+    double vloc[LT];
+    const double* __restrict__ vrow = a.vr + size_t(t) * 16;
+#pragma unroll
+    for (int b2 = 0; b2 < LT; ++b2) vloc[b2] = vrow[b2];
+    double dlane = vrow[LT];
+#pragma unroll
+    for (int b2 = 0; b2 < LGT; ++b2)
+        if (!(tid >> b2 & 1u)) dlane += vloc[b2];
     double rr[R];  // Re(beta conj(mu) x): weight of d(x) in the gradient
     if (BWD) {
 #pragma unroll
@@ -228,7 +251,10 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     double2 q[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        double d = dg[r];
+        double d = dg[r] + dlane;
+#pragma unroll
+        for (int b2 = LGT; b2 < LT; ++b2)
+            if (!(r >> (b2 - LGT) & 1)) d += vloc[b2];
         for (int g = 0; g < a.gd; ++g) d += cf[2 * a.ga + g] * double(a.dcnt[g] - __popc(xg[r] & a.dmask[g]));
         const double dr = a.sg_r + a.sb_r * d, di = a.sg_i + a.sb_i * d;
         q[r].x = dr * acc[r].x - di * acc[r].y;

@@ -54,7 +54,7 @@ struct Plan {
 
     // workspace offsets (bytes)
     size_t off_meta_idx = 0, off_meta_w = 0, off_coef = 0, off_stats = 0, off_udiag = 0, off_buf0 = 0, off_buf1 = 0;
-    size_t off_tape = 0, off_chain = 0, off_ge = 0, off_wtot = 0, off_members = 0, off_meta2 = 0, off_pp0 = 0, off_pp1 = 0;
+    size_t off_tape = 0, off_chain = 0, off_ge = 0, off_wtot = 0, off_members = 0, off_meta2 = 0, off_pp0 = 0, off_pp1 = 0, off_split = 0;
     size_t state_bytes = 0;  // B * dim * 16
     size_t total_fwd = 0;
     int chain_slots = 0;
@@ -276,6 +276,8 @@ inline size_t carve(Plan& pl, bool need_tape, bool need_backward, int chain_slot
     pl.off_buf1 = take(pl.state_bytes);
     pl.off_pp0 = take(pl.state_bytes);  // partial vectors of the chained passes
     pl.off_pp1 = take(pl.state_bytes);
+    // split interaction diagonal for the two tile layouts: utt[2][4096] + vr[2][tiles][16]
+    pl.off_split = take(2 * (4096 + (pl.dim >> 12 ? (pl.dim >> 12) : 1) * 16) * sizeof(double));
     pl.total_fwd = off;
     pl.off_tape = need_tape ? take(size_t(pl.T + 1) * pl.state_bytes) : 0;
     pl.chain_slots = chain_slots;

@@ -130,6 +130,49 @@ __global__ void k_build_udiag(double* __restrict__ udiag, const double* __restri
     udiag[x] = s;
 }
 
+// split form of the interaction diagonal for one tile layout (chain_kernels.hpp):
+//   U(x) = utt[i] + vr[t][12] + sum_{tile bits a with n_a(i)=1} vr[t][a],   x = x(t, i)
+__global__ void k_build_split(double* __restrict__ utt, double* __restrict__ vr, const double* __restrict__ u_pairs,
+                              int N, int lo, int hs, int hb, unsigned tiles) {
+    constexpr int LT = 12;
+    const unsigned id = blockIdx.x * blockDim.x + threadIdx.x;
+    auto gbit = [&](int b) { return b < lo ? b : hs + (b - lo); };          // tile bit -> index bit
+    auto upair = [&](int ib, int jb) {                                       // index bits -> U_ij
+        int qi = N - 1 - ib, qj = N - 1 - jb;
+        if (qi > qj) { int tmp = qi; qi = qj; qj = tmp; }
+        return u_pairs[qi * (2 * N - qi - 1) / 2 + (qj - qi - 1)];
+    };
+    if (id < (1u << LT)) {
+        double s = 0.0;
+        for (int a = 0; a < LT; ++a)
+            for (int b = a + 1; b < LT; ++b)
+                if (!(id >> a & 1u) && !(id >> b & 1u)) s += upair(gbit(a), gbit(b));
+        utt[id] = s;
+    } else if (id - (1u << LT) < tiles) {
+        const unsigned t = id - (1u << LT);
+        const int midlow = hs - lo;
+        const unsigned xbase = ((t & ((1u << midlow) - 1u)) << lo) | ((t >> midlow) << (hs + hb));
+        uint32_t tile_bits = 0;
+        for (int a = 0; a < LT; ++a) tile_bits |= 1u << gbit(a);
+        double* row = vr + size_t(t) * 16;
+        double urr = 0.0;
+        for (int ib = 0; ib < N; ++ib) {
+            if (tile_bits >> ib & 1u) continue;
+            if (xbase >> ib & 1u) continue;  // n = 0
+            for (int jb = ib + 1; jb < N; ++jb)
+                if (!(tile_bits >> jb & 1u) && !(xbase >> jb & 1u)) urr += upair(ib, jb);
+        }
+        for (int a = 0; a < LT; ++a) {
+            double v = 0.0;
+            for (int jb = 0; jb < N; ++jb)
+                if (!(tile_bits >> jb & 1u) && !(xbase >> jb & 1u)) v += upair(gbit(a), jb);
+            row[a] = v;
+        }
+        row[LT] = urr;
+        for (int c = LT + 1; c < 16; ++c) row[c] = 0.0;
+    }
+}
+
 // g_u[pair] = sum_x n_i n_j wtot[x]
 __global__ void k_ugrad(double* __restrict__ g_u, const double* __restrict__ wtot, int N, uint32_t dim) {
     __shared__ double lds[8];
@@ -718,6 +761,18 @@ int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_
     } else {
         HIP_TRY(hipMemsetAsync(udiag, 0, pl.dim * sizeof(double), stream));
     }
+    if (pl.N > 12 && pl.N <= 24) {  // split diagonal for the two tile layouts of the chained passes
+        const unsigned tiles = unsigned(pl.dim >> 12);
+        double* split = reinterpret_cast<double*>(ws + pl.off_split);
+        const size_t per_layout = 4096 + size_t(tiles) * 16;
+        const int lay[2][3] = {{12, 12, 0}, {24 - pl.N, 12, pl.N - 12}};  // (lo, hs, hb) of layouts A and B
+        for (int l = 0; l < 2; ++l) {
+            double* utt = split + l * per_layout;
+            hipLaunchKernelGGL(k_build_split, dim3((4096 + tiles + 255) / 256), dim3(256), 0, stream, utt, utt + 4096,
+                               p->u_pairs, pl.N, lay[l][0], lay[l][1], lay[l][2], tiles);
+            LAUNCH_CHECK();
+        }
+    }
     return RYDIFF_OK;
 }
 
@@ -831,12 +886,17 @@ struct ChainStep {
     const double2* x_sta = nullptr;
     double cb_fin_r = 0, cb_fin_i = 0, cb_sta_r = 0, cb_sta_i = 0;
     double* wtot = nullptr;
+    // fused expectation (forward)
+    const double* obs = nullptr;
+    double* expect_slot = nullptr;
+    int n_obs = 0;
+    long exp_ostride = 0;
 };
 
 template <int LGT, bool CPLX, bool BWD>
 int launch_chain_t(const ChainArgs& ca, unsigned tiles, int B, hipStream_t stream) {
     static bool attr_set = false;
-    const size_t lds = (size_t(1) << kTileBits) * sizeof(double2) + (BWD ? 256 : 0);
+    const size_t lds = (size_t(1) << kTileBits) * sizeof(double2) + 256;
     auto kern = k_chain<kTileBits, LGT, CPLX, BWD>;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
@@ -863,7 +923,12 @@ int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, hipStream_t s
     ca.p = cs.p;
     ca.v_out = cs.v_out;
     ca.q_out = cs.q_out;
-    ca.udiag = reinterpret_cast<const double*>(ws + pl.off_udiag);
+    {
+        const size_t per_layout = 4096 + size_t(pl.dim >> kTileBits) * 16;
+        const double* split = reinterpret_cast<const double*>(ws + pl.off_split) + size_t(cs.layout) * per_layout;
+        ca.utt = split;
+        ca.vr = split + 4096;
+    }
     const double* coef = reinterpret_cast<const double*>(ws + pl.off_coef);
     ca.coef_fin = coef + size_t(std::max(cs.fin_stage, 0)) * pl.NC;
     ca.coef_sta = coef + size_t(std::max(cs.sta_stage, 0)) * pl.NC;
@@ -892,6 +957,10 @@ int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, hipStream_t s
         ca.dmask[g] = pl.gd.amp_index_mask[g];
         ca.dcnt[g] = pl.gd.count[g];
     }
+    ca.obs = cs.obs;
+    ca.expect_slot = cs.expect_slot;
+    ca.n_obs = cs.n_obs;
+    ca.exp_ostride = cs.exp_ostride;
     if (cs.bwd) {
         double* ge = reinterpret_cast<double*>(ws + pl.off_ge);
         const long ge_rec = long(kGradReplicas) * (pl.NC + 1);
@@ -922,9 +991,9 @@ int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, hipStream_t s
 //   dst(i)   : where the complete output of factor i (0-based) goes, or nullptr to skip storing it (only legal for the last)
 //   on_done(i, ptr): called after the launch that completed factor i
 // skip_last_finish: do not finish the last factor (its output is not needed) — used by the backward recompute.
-template <class DstFn, class DoneFn>
+template <class DstFn, class DoneFn, class ExpFn>
 int run_chain(const Runtime& rt, char* ws, const std::vector<ChainItem>& items, const double2* start, DstFn dst, DoneFn on_done,
-              bool skip_last_finish, hipStream_t stream) {
+              ExpFn exp_slot, bool skip_last_finish, hipStream_t stream) {
     const Plan& pl = rt.pl;
     double2* pp[2] = {reinterpret_cast<double2*>(ws + pl.off_pp0), reinterpret_cast<double2*>(ws + pl.off_pp1)};
     const int F = int(items.size());
@@ -946,6 +1015,7 @@ int run_chain(const Runtime& rt, char* ws, const std::vector<ChainItem>& items, 
         if (cs.has_p) cs.fin = items[j - 1].s;
         if (cs.has_q) cs.sta = items[j].s;
         if (cs.has_p && !cs.v_out) return fail(RYDIFF_EINVAL, "internal: chain destination missing");
+        if (cs.has_p) exp_slot(j - 1, cs);
         int rc = launch_chain(rt, ws, cs, stream);
         if (rc) return rc;
         if (cs.has_p) {
@@ -1114,14 +1184,16 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
             flip ^= 1;
             return buf[flip];
         };
-        auto done = [&](int i, const double2* v) -> int {
-            if (want_exp && step_of_end[i]) {
-                hipLaunchKernelGGL(k_expect_diag, dim3(red_blocks, pl.B), dim3(256), 0, stream, v, obs, expect_out, pl.n_obs, pl.T + 1, step_of_end[i], pl.B, uint32_t(pl.dim));
-                LAUNCH_CHECK();
+        auto done = [&](int, const double2*) -> int { return RYDIFF_OK; };
+        auto exp_slot = [&](int i, ChainStep& cs) {
+            if (want_exp && step_of_end[i]) {  // the pass that completes a step's last factor also reduces <O>
+                cs.obs = obs;
+                cs.n_obs = pl.n_obs;
+                cs.exp_ostride = long(pl.T + 1) * pl.B;
+                cs.expect_slot = expect_out + size_t(step_of_end[i]) * pl.B;
             }
-            return RYDIFF_OK;
         };
-        rc = run_chain(rt, ws, all, cur, dst, done, false, stream);
+        rc = run_chain(rt, ws, all, cur, dst, done, exp_slot, false, stream);
         if (rc) return rc;
         return RYDIFF_OK;
     }
@@ -1201,7 +1273,8 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
             for (int i = 1; i < M; ++i) xs[i] = chainbuf + size_t(i - 1) * sv;
             auto dst = [&](int i) -> double2* { return chainbuf + size_t(i) * sv; };
             auto done = [&](int, const double2*) -> int { return RYDIFF_OK; };
-            rc = run_chain(rt, ws, chain, xs[0], dst, done, true, stream);
+            auto no_exp = [&](int, ChainStep&) {};
+            rc = run_chain(rt, ws, chain, xs[0], dst, done, no_exp, true, stream);
             if (rc) return rc;
         } else {
             for (int i = 1; i < M; ++i) {
