@@ -13,7 +13,7 @@ import subprocess
 from pathlib import Path
 
 _CSRC = Path(__file__).resolve().parent / "csrc"
-_LIB_PATH = _CSRC / "librydiff.so"
+_LIB_PATH = Path(os.environ.get("RYDIFF_LIB", _CSRC / "librydiff.so"))  # RYDIFF_LIB: A/B builds for tuning
 
 RYDIFF_OK = 0
 RYDIFF_EINVAL = -1

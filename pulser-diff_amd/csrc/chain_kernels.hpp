@@ -19,6 +19,17 @@
 
 constexpr int kTileBits = 12;
 
+// Streaming store: the vectors written by a pass are read next by OTHER workgroups in the other tile layout, never by
+// this one, so there is no point keeping the lines dirty in this XCD's L2 until the end-of-kernel write-back.
+__device__ __forceinline__ void stream_store(double2* p, const double2& v) {
+#ifdef RYDIFF_PLAIN_STORES
+    *p = v;
+#else
+    __builtin_nontemporal_store(v.x, &p->x);
+    __builtin_nontemporal_store(v.y, &p->y);
+#endif
+}
+
 struct ChainArgs {
     const double2* u;      // complete v_{j-1}
     const double2* p;      // partial of factor j (unused when !has_p)
@@ -129,6 +140,10 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     const int midlow = a.hs - a.lo;
     const unsigned xbase = ((t & ((1u << midlow) - 1u)) << a.lo) | ((t >> midlow) << (a.hs + a.hb));
 
+#ifdef RYDIFF_STAGGER
+    // de-synchronise the workgroups' load / store phases (all tiles are co-resident and start together)
+    for (unsigned sl = 0; sl < (blockIdx.x % RYDIFF_STAGGER_PHASES); ++sl) __builtin_amdgcn_s_sleep(RYDIFF_STAGGER);
+#endif
     double2 uu[R], acc[R];
     unsigned xg[R];
 #pragma unroll
@@ -168,7 +183,11 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
             const uint32_t mask = a.fin_mask[g];
             if (!mask) continue;
             double2 ts[R], ds[R];
+#ifndef RYDIFF_ABLATE_COMPUTE
             partner_sums<LT, LGT, CPLX || BWD>(tile, uu, mask, tid, ts, ds);
+#else
+            for (int r = 0; r < R; ++r) { ts[r] = uu[r]; ds[r] = uu[r]; }
+#endif
             const double cr = cf[g], ci = cf[a.ga + g];
             // c*s1 + conj(c)*s0 = cr*(s1+s0) + i*ci*(s1-s0);  k1 = beta*cr, k2 = beta*i*ci
             const double k1r = a.fb_r * cr, k1i = a.fb_i * cr;
@@ -206,7 +225,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     }
     if (a.write_v) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) a.v_out[boff + xg[r]] = acc[r];
+        for (int r = 0; r < R; ++r) stream_store(a.v_out + boff + xg[r], acc[r]);
     }
     if (!BWD && a.obs) {  // <v|O|v> for diagonal observables, straight from the registers that hold v
         for (int o = 0; o < a.n_obs; ++o) {
@@ -264,7 +283,11 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
         const uint32_t mask = a.sta_mask[g];
         if (!mask) continue;
         double2 ts[R], ds[R];
+#ifndef RYDIFF_ABLATE_COMPUTE
         partner_sums<LT, LGT, CPLX || BWD>(tile, acc, mask, tid, ts, ds);
+#else
+        for (int r = 0; r < R; ++r) { ts[r] = acc[r]; ds[r] = acc[r]; }
+#endif
         const double cr = cf[g], ci = cf[a.ga + g];
         const double k1r = a.sb_r * cr, k1i = a.sb_i * cr;
         const double k2r = -a.sb_i * ci, k2i = a.sb_r * ci;
@@ -291,5 +314,5 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
         }
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) a.q_out[boff + xg[r]] = q[r];
+    for (int r = 0; r < R; ++r) stream_store(a.q_out + boff + xg[r], q[r]);
 }

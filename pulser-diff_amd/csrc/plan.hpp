@@ -58,6 +58,7 @@ struct Plan {
     size_t state_bytes = 0;  // B * dim * 16
     size_t total_fwd = 0;
     int chain_slots = 0;
+    int tape_mode = 0;
 };
 
 inline size_t align_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
@@ -258,7 +259,9 @@ inline bool build_plan(const RydProblem* p, Plan& pl, std::string& err) {
 }
 
 // Carve the workspace. `chain_slots` = number of intermediate state buffers the backward recompute needs.
-inline size_t carve(Plan& pl, bool need_tape, bool need_backward, int chain_slots) {
+// tape_mode: 0 none | 1 one state per tsave | 2 FULL: the output of every factor pass (no recompute in the adjoint sweep;
+// needs total_factors+1 states of HBM — e.g. 156 GiB for N=20, T=1000, which an MI355X's 288 GB holds)
+inline size_t carve(Plan& pl, int tape_mode, bool need_backward, int chain_slots, int64_t total_factors = 0) {
     const size_t E = pl.stages.size();
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -279,7 +282,9 @@ inline size_t carve(Plan& pl, bool need_tape, bool need_backward, int chain_slot
     // split interaction diagonal for the two tile layouts: utt[2][4096] + vr[2][tiles][16]
     pl.off_split = take(2 * (4096 + (pl.dim >> 12 ? (pl.dim >> 12) : 1) * 16) * sizeof(double));
     pl.total_fwd = off;
-    pl.off_tape = need_tape ? take(size_t(pl.T + 1) * pl.state_bytes) : 0;
+    pl.tape_mode = tape_mode;
+    if (tape_mode == 2) pl.off_tape = take(size_t(total_factors + 1) * pl.state_bytes);
+    else pl.off_tape = tape_mode ? take(size_t(pl.T + 1) * pl.state_bytes) : 0;
     pl.chain_slots = chain_slots;
     if (need_backward) {
         pl.off_chain = take(size_t(chain_slots > 0 ? chain_slots : 1) * pl.state_bytes);

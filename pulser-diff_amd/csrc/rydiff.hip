@@ -35,6 +35,7 @@ constexpr int kGradReplicas = 64;
 
 static thread_local std::string g_last_error;
 static int g_kernel_variant = 0;
+constexpr int kTileBitsHost = 12;
 
 static int fail(int code, const std::string& msg) {
     g_last_error = msg;
@@ -700,7 +701,7 @@ void fill_info(const Runtime& rt, double lo, double hi, size_t ws, RydPlanInfo* 
 }
 
 // common prologue of forward / backward: plan, (optional) stats, carve, upload metadata, expand coefficients, udiag
-int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_t workspace_bytes, bool need_tape,
+int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_t workspace_bytes, int need_tape,
             bool need_backward, hipStream_t stream, Runtime& rt) {
     std::string err;
     if (!build_plan(p, rt.pl, err)) return fail(err.find("not implemented") != std::string::npos ? RYDIFF_ENOTIMPL : RYDIFF_EINVAL, err);
@@ -718,7 +719,8 @@ int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_
     int rc = finish_runtime(rt, lo, hi);
     if (rc) return rc;
     Plan& pl = rt.pl;
-    const size_t need = carve(pl, need_tape, need_backward, std::max(rt.max_step_factors - 1, 1));
+    if (need_tape == 2 && !(pl.N > kTileBitsHost && pl.N <= 2 * kTileBitsHost && g_kernel_variant != 1)) need_tape = 1;  // full tape only with chained passes
+    const size_t need = carve(pl, need_tape, need_backward, std::max(rt.max_step_factors - 1, 1), rt.total_factors);
     if (workspace_bytes < need)
         return fail(RYDIFF_EWORKSPACE, "workspace too small: need " + std::to_string(need) + " bytes, got " + std::to_string(workspace_bytes));
     char* ws = static_cast<char*>(workspace);
@@ -1135,7 +1137,9 @@ int rydiff_plan(const RydProblem* p, int need_tape, int need_backward, void* scr
     if (rc) return rc;
     rc = finish_runtime(rt, lo, hi);
     if (rc) return rc;
-    const size_t ws = carve(rt.pl, need_tape != 0, need_backward != 0, std::max(rt.max_step_factors - 1, 1));
+    int tm = need_tape;
+    if (tm == 2 && !(rt.pl.N > kTileBitsHost && rt.pl.N <= 2 * kTileBitsHost && g_kernel_variant != 1)) tm = 1;
+    const size_t ws = carve(rt.pl, tm, need_backward != 0, std::max(rt.max_step_factors - 1, 1), rt.total_factors);
     fill_info(rt, lo, hi, ws, info);
     return RYDIFF_OK;
 }
@@ -1145,7 +1149,7 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!psi0) return fail(RYDIFF_EINVAL, "null psi0");
     Runtime rt;
-    int rc = prepare(p, info, workspace, workspace_bytes, need_tape != 0 && !states_out, false, stream, rt);
+    int rc = prepare(p, info, workspace, workspace_bytes, states_out ? 0 : need_tape, false, stream, rt);
     if (rc) return rc;
     const Plan& pl = rt.pl;
     char* ws = static_cast<char*>(workspace);
@@ -1179,7 +1183,9 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
             }
         }
         int flip = 0;
+        const bool full_tape = (pl.tape_mode == 2) && !states_out;
         auto dst = [&](int i) -> double2* {
+            if (full_tape) return tape + size_t(i + 1) * sv;  // entry g = output of global factor g (entry 0 = psi0)
             if (step_of_end[i] && tape) return tape + size_t(step_of_end[i]) * sv;
             flip ^= 1;
             return buf[flip];
@@ -1230,7 +1236,7 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!states && !need_tape) return fail(RYDIFF_EINVAL, "backward needs the trajectory: pass states or use the workspace tape");
     Runtime rt;
-    int rc = prepare(p, info, workspace, workspace_bytes, need_tape != 0 && !states, true, stream, rt);
+    int rc = prepare(p, info, workspace, workspace_bytes, states ? 0 : need_tape, true, stream, rt);
     if (rc) return rc;
     const Plan& pl = rt.pl;
     char* ws = static_cast<char*>(workspace);
@@ -1254,9 +1260,18 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
     if (wtot) HIP_TRY(hipMemsetAsync(wtot, 0, pl.dim * sizeof(double), stream));
     dim3 grid(unsigned((pl.dim + 255) / 256), pl.B);
     int cl = 0;
+    // where the state at tsave[k] lives: one entry per tsave, or (full tape) one entry per factor pass
+    const bool full_tape = !states && pl.tape_mode == 2;
+    std::vector<int64_t> fprefix(pl.T + 1, 0);
+    for (int k = 0; k < pl.T; ++k) {
+        int64_t f = 0;
+        for (int e = pl.step_begin[k]; e < pl.step_begin[k + 1]; ++e) f += int64_t(pl.stages[e].nsub) * rt.poly.degree;
+        fprefix[k + 1] = fprefix[k] + f;
+    }
+    auto state_at = [&](int k) -> const double2* { return tape + size_t(full_tape ? fprefix[k] : k) * sv; };
     // cotangent at the final time
     hipLaunchKernelGGL(k_inject, grid, dim3(256), 0, stream, lam[cl], gst ? gst + size_t(pl.T) * sv : nullptr,
-                       tape + size_t(pl.T) * sv, obs, have_gexp ? grad_expect : nullptr, pl.n_obs, pl.T + 1, pl.T, pl.B,
+                       state_at(pl.T), obs, have_gexp ? grad_expect : nullptr, pl.n_obs, pl.T + 1, pl.T, pl.B,
                        uint32_t(pl.dim), 1);
     LAUNCH_CHECK();
 
@@ -1268,8 +1283,10 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
         if (M - 1 > pl.chain_slots) return fail(RYDIFF_EWORKSPACE, "internal: chain buffers too small");
         // recompute the factor inputs x_0 .. x_{M-1}
         xs.assign(M + 1, nullptr);
-        xs[0] = tape + size_t(k) * sv;
-        if (chain_enabled(rt) && M > 1) {
+        xs[0] = state_at(k);
+        if (full_tape) {
+            for (int i = 1; i < M; ++i) xs[i] = tape + size_t(fprefix[k] + i) * sv;  // every factor input is on the tape
+        } else if (chain_enabled(rt) && M > 1) {
             for (int i = 1; i < M; ++i) xs[i] = chainbuf + size_t(i - 1) * sv;
             auto dst = [&](int i) -> double2* { return chainbuf + size_t(i) * sv; };
             auto done = [&](int, const double2*) -> int { return RYDIFF_OK; };
@@ -1284,7 +1301,7 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
                 xs[i] = dst;
             }
         }
-        xs[M] = tape + size_t(k + 1) * sv;
+        xs[M] = state_at(k + 1);
         auto dot_h = [&](int stage, const double2* g, const double2* xout) -> int {
             if (!g_tsave) return RYDIFF_OK;
             DotHArgs da{};
@@ -1348,7 +1365,7 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
         }
         if (gst || have_gexp) {
             hipLaunchKernelGGL(k_inject, grid, dim3(256), 0, stream, lam[cl], gst ? gst + size_t(k) * sv : nullptr,
-                               tape + size_t(k) * sv, obs, have_gexp ? grad_expect : nullptr, pl.n_obs, pl.T + 1, k, pl.B,
+                               state_at(k), obs, have_gexp ? grad_expect : nullptr, pl.n_obs, pl.T + 1, k, pl.B,
                                uint32_t(pl.dim), 0);
             LAUNCH_CHECK();
         }

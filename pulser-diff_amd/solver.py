@@ -49,6 +49,7 @@ class ProblemSpec:
     solver: SolverType = SolverType.KRYLOV_SE
     tol: float = 0.0
     store_states: bool = True
+    tape: str = "auto"  # with store_states=False and gradients: "steps" | "full" | "auto" (full when it fits in HBM)
     options: dict = field(default_factory=dict)
 
     def solver_code(self) -> int:
@@ -146,14 +147,22 @@ class _RydbergEvolve(torch.autograd.Function):
         n_t = len(ts_host)
         call = _Call(spec, amp_c, det_c, u_c, ts_host, batch, obs_c)
         needs_grad = any(ctx.needs_input_grad[:5])
-        need_tape = bool(needs_grad and not spec.store_states)
+        need_tape = int(bool(needs_grad and not spec.store_states))
         with torch.cuda.device(dev):
             stream = _stream_ptr(dev)
             scratch = torch.empty(_native.PLAN_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
             info = _native.RydPlanInfo()
             # with the trajectory kept in the workspace tape, size the workspace for the backward sweep right away
-            _native.check(L.rydiff_plan(ctypes.byref(call.problem), int(need_tape), int(need_tape), _ptr(scratch),
-                                        stream, ctypes.byref(info)))
+            if need_tape and spec.tape in ("auto", "full"):
+                # FULL tape (every factor output kept, no recompute in the adjoint sweep) when HBM has room for it
+                _native.check(L.rydiff_plan(ctypes.byref(call.problem), 2, 1, _ptr(scratch), stream, ctypes.byref(info)))
+                free_bytes, _total = torch.cuda.mem_get_info(dev)
+                reusable = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+                if spec.tape == "full" or info.workspace_bytes < 0.8 * (free_bytes + reusable):
+                    need_tape = 2
+            if need_tape != 2:
+                _native.check(L.rydiff_plan(ctypes.byref(call.problem), need_tape, need_tape, _ptr(scratch),
+                                            stream, ctypes.byref(info)))
             workspace = torch.empty(info.workspace_bytes, dtype=torch.uint8, device=dev)
             states = (torch.empty((n_t, batch, dim), dtype=torch.complex128, device=dev) if spec.store_states
                       else torch.empty((0, batch, dim), dtype=torch.complex128, device=dev))
@@ -162,13 +171,14 @@ class _RydbergEvolve(torch.autograd.Function):
             _native.check(L.rydiff_forward(ctypes.byref(call.problem), ctypes.byref(info), _ptr(psi_c),
                                            _ptr(states) if spec.store_states else None,
                                            _ptr(expect) if n_obs else None, _ptr(workspace),
-                                           workspace.numel(), int(need_tape), stream))
+                                           workspace.numel(), need_tape, stream))
         ctx.spec = spec
         ctx.info = info
         ctx.tsave_host = ts_host
         ctx.tsave_meta = (tsave.device, tsave.dtype)
         ctx.in_dtypes = (amp.dtype, det.dtype, u_pairs.dtype, psi0.dtype)
         ctx.need_tape = need_tape
+        ctx.keep_tape = True  # retain_graph=True callers may run backward again
         ctx.tape_workspace = workspace if need_tape else None
         ctx.save_for_backward(amp_c, det_c, u_c, psi_c, obs_c if obs_c is not None else torch.empty(0, device=dev),
                               states)
@@ -219,6 +229,8 @@ class _RydbergEvolve(torch.autograd.Function):
                                             _ptr(g_expect) if (g_expect is not None and obs is not None) else None,
                                             _ptr(g_amp), _ptr(g_det), _ptr(g_u), _ptr(g_ts), _ptr(g_psi),
                                             _ptr(workspace), workspace.numel(), int(ctx.need_tape), stream))
+            if ctx.need_tape:
+                ctx.tape_workspace = None if not ctx.keep_tape else ctx.tape_workspace
         a_dt, d_dt, u_dt, p_dt = ctx.in_dtypes
         if g_amp is not None:
             g_amp = g_amp.to(a_dt) if a_dt.is_complex else g_amp.real.to(a_dt)
