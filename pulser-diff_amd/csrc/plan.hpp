@@ -54,7 +54,7 @@ struct Plan {
 
     // workspace offsets (bytes)
     size_t off_meta_idx = 0, off_meta_w = 0, off_coef = 0, off_stats = 0, off_udiag = 0, off_buf0 = 0, off_buf1 = 0;
-    size_t off_tape = 0, off_chain = 0, off_ge = 0, off_wtot = 0, off_members = 0, off_meta2 = 0, off_pp0 = 0, off_pp1 = 0, off_split = 0;
+    size_t off_tape = 0, off_chain = 0, off_ge = 0, off_wtot = 0, off_members = 0, off_meta2 = 0, off_pp0 = 0, off_pp1 = 0, off_split = 0, off_ptable = 0, ptable_bytes = 0;
     size_t state_bytes = 0;  // B * dim * 16
     size_t total_fwd = 0;
     int chain_slots = 0;
@@ -262,6 +262,8 @@ inline bool build_plan(const RydProblem* p, Plan& pl, std::string& err) {
 // tape_mode: 0 none | 1 one state per tsave | 2 FULL: the output of every factor pass (no recompute in the adjoint sweep;
 // needs total_factors+1 states of HBM — e.g. 156 GiB for N=20, T=1000, which an MI355X's 288 GB holds)
 inline size_t carve(Plan& pl, int tape_mode, bool need_backward, int chain_slots, int64_t total_factors = 0) {
+    // factor table of the persistent small-N kernel: 40 bytes per factor pass
+    pl.ptable_bytes = pl.N <= 12 ? size_t(total_factors) * 40 + 64 : 0;
     const size_t E = pl.stages.size();
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -281,6 +283,7 @@ inline size_t carve(Plan& pl, int tape_mode, bool need_backward, int chain_slots
     pl.off_pp1 = take(pl.state_bytes);
     // split interaction diagonal for the two tile layouts: utt[2][4096] + vr[2][tiles][16]
     pl.off_split = take(2 * (4096 + (pl.dim >> 12 ? (pl.dim >> 12) : 1) * 16) * sizeof(double));
+    pl.off_ptable = take(pl.ptable_bytes);
     pl.total_fwd = off;
     pl.tape_mode = tape_mode;
     if (tape_mode == 2) pl.off_tape = take(size_t(total_factors + 1) * pl.state_bytes);

@@ -1091,6 +1091,35 @@ int run_chain_bwd(const Runtime& rt, char* ws, const std::vector<ChainItem>& ite
     return RYDIFF_OK;
 }
 
+// ---- persistent small-N forward (k_persist) ------------------------------------------------------------------------
+bool persist_enabled(const Runtime& rt) { return g_kernel_variant != 1 && rt.pl.N <= kTileBits; }
+
+template <int LT, bool CPLX>
+int launch_persist_t(const PersistArgs& pa, int B, hipStream_t stream) {
+    constexpr int LGT = LT < 10 ? LT : 10;
+    hipLaunchKernelGGL((k_persist<LT, LGT, CPLX>), dim3(B), dim3(1 << LGT), 0, stream, pa);
+    LAUNCH_CHECK();
+    return RYDIFF_OK;
+}
+
+template <bool CPLX>
+int launch_persist(int N, const PersistArgs& pa, int B, hipStream_t stream) {
+    switch (N) {
+        case 1: return launch_persist_t<1, CPLX>(pa, B, stream);
+        case 2: return launch_persist_t<2, CPLX>(pa, B, stream);
+        case 3: return launch_persist_t<3, CPLX>(pa, B, stream);
+        case 4: return launch_persist_t<4, CPLX>(pa, B, stream);
+        case 5: return launch_persist_t<5, CPLX>(pa, B, stream);
+        case 6: return launch_persist_t<6, CPLX>(pa, B, stream);
+        case 7: return launch_persist_t<7, CPLX>(pa, B, stream);
+        case 8: return launch_persist_t<8, CPLX>(pa, B, stream);
+        case 9: return launch_persist_t<9, CPLX>(pa, B, stream);
+        case 10: return launch_persist_t<10, CPLX>(pa, B, stream);
+        case 11: return launch_persist_t<11, CPLX>(pa, B, stream);
+        default: return launch_persist_t<12, CPLX>(pa, B, stream);
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -1171,6 +1200,44 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
         LAUNCH_CHECK();
     }
     std::vector<ChainItem> chain;
+    if (persist_enabled(rt)) {
+        // whole trajectory in one launch; the factor table goes to the (otherwise unused) first ping-pong buffer region
+        std::vector<PersistFactor> table;
+        for (int k = 0; k < pl.T; ++k) {
+            build_step_chain(rt, k, chain);
+            for (size_t i = 0; i < chain.size(); ++i)
+                table.push_back({chain[i].s.gr, chain[i].s.gi, chain[i].s.br, chain[i].s.bi, chain[i].stage,
+                                 i + 1 == chain.size() ? k + 1 : 0});
+        }
+        const size_t tbytes = table.size() * sizeof(PersistFactor);
+        if (tbytes > pl.ptable_bytes) return fail(RYDIFF_EWORKSPACE, "internal: factor table does not fit");
+        PersistFactor* dtab = reinterpret_cast<PersistFactor*>(ws + pl.off_ptable);
+        HIP_TRY(hipMemcpyAsync(dtab, table.data(), tbytes, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        PersistArgs pa{};
+        pa.psi0 = static_cast<const double2*>(psi0);
+        pa.states = tape;
+        pa.udiag = reinterpret_cast<const double*>(ws + pl.off_udiag);
+        pa.coef = reinterpret_cast<const double*>(ws + pl.off_coef);
+        pa.coef_bstride = pl.Bc > 1 ? long(pl.stages.size()) * pl.NC : 0;
+        pa.NC = pl.NC;
+        pa.factors = dtab;
+        pa.n_factors = int(table.size());
+        pa.obs = want_exp ? obs : nullptr;
+        pa.expect = expect_out;
+        pa.n_obs = want_exp ? pl.n_obs : 0;
+        pa.n_tsave = pl.T + 1;
+        pa.B = pl.B;
+        pa.dim = uint32_t(pl.dim);
+        pa.ga = pl.ga.n;
+        pa.gd = pl.gd.n;
+        for (int g = 0; g < pl.ga.n; ++g) pa.amask[g] = pl.ga.amp_index_mask[g];
+        for (int g = 0; g < pl.gd.n; ++g) {
+            pa.dmask[g] = pl.gd.amp_index_mask[g];
+            pa.dcnt[g] = pl.gd.count[g];
+        }
+        return (rt.flags & 1) ? launch_persist<true>(pl.N, pa, pl.B, stream) : launch_persist<false>(pl.N, pa, pl.B, stream);
+    }
     if (chain_enabled(rt)) {
         // one chain over the whole run: factor i of step k; complete outputs at step ends go to the tape
         std::vector<ChainItem> all;
