@@ -171,6 +171,13 @@ def main() -> None:
     achieved = alg_bytes / (launch_us * 1e-6) / 1e9
     fwd_steps_per_s = T * batch / (fwd_ms * 1e-3)
 
+    # HBM/fabric bytes per launch from the PMC passes committed under profiles/ (bench.py cannot run rocprofv3 on itself)
+    traffic, traffic_src = None, None
+    pmc = ROOT / "profiles" / "r01_pmc_traffic_chain.json"
+    if args.workload == "c3" and batch == 1 and args.variant == 0 and pmc.exists():
+        traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch"]
+        traffic_src = "profiles/r01_pmc_traffic_chain.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2)"
+
     out = {
         "metric": "time-steps/sec (fwd+grad)",
         "value": value,
@@ -192,8 +199,8 @@ def main() -> None:
         "loss": float(loss),
         "roofline": {"bound": "hbm", "kernel": "k_factor (matrix-free y = gamma*x + beta*H x)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "avg_launch_us": launch_us, "algorithmic_bytes_per_launch": alg_bytes,
-                     "launches": total_factors},
+                     "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": launch_us,
+                     "algorithmic_bytes_per_launch": alg_bytes, "launches": total_factors},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -211,7 +218,11 @@ def cpu_baseline(n_qubits, coords, omega, delta, seg_len, n_steps):
     sparse H cannot run at all (it materialises a dense 2^N x 2^N gradient)."""
     from oracle import restatement as R
 
-    torch.set_num_threads(os.cpu_count() or 1)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
     amp = torch.cat([omega.repeat_interleave(seg_len), torch.zeros(1, dtype=torch.float64)])
     det = torch.cat([delta.repeat_interleave(seg_len), torch.zeros(1, dtype=torch.float64)])
     seq = R.SampledGlobalSequence(amp, det, torch.zeros_like(amp))
