@@ -140,6 +140,15 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
 int rydiff_apply_hamiltonian(const RydProblem* p, const double* c_amp_reim, const double* c_det,
                              const void* x, void* y, void* workspace, size_t workspace_bytes, void* stream);
 
+/* One factor pass  y = gamma*x + beta*H x + sum_k rc_k * remote_k  on DEVICE buffers, coefficients given per term on the
+ * HOST like rydiff_apply_hamiltonian.  `remote` (HOST array of n_remote DEVICE pointers, each [B][2^N]) carries the vectors
+ * of other GPUs in a state-sharded run: the flip terms of the qubits that select the GPU (pulser-diff_amd/sharded.py;
+ * SURVEY.md section 8e, BASELINE config 5).  reuse_diag != 0 skips rebuilding the interaction diagonal kept at the start
+ * of `workspace` (>= 8 * 2^N bytes) by a previous call with the same u_pairs. */
+int rydiff_apply_factor(const RydProblem* p, const double* c_amp_reim, const double* c_det, const double* gamma_reim,
+                        const double* beta_reim, const void* x, void* y, int n_remote, const void* const* remote,
+                        const double* remote_coef_reim, int reuse_diag, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Host-only helper (no GPU needed): design the product-form polynomial used for exp(-i*rho*x), x in [-1,1].
  * Writes the degree to *degree and roots (re,im interleaved) to roots_reim[2*max_degree]; returns the
  * measured max |p(x) - exp(-i rho x)| on a test grid in *max_err.  Exposed so the host logic is testable on CPU. */

@@ -69,6 +69,7 @@ EXPORTS = (
     "rydiff_forward",
     "rydiff_backward",
     "rydiff_apply_hamiltonian",
+    "rydiff_apply_factor",
     "rydiff_design_polynomial",
     "rydiff_set_kernel_variant",
     "rydiff_last_error",
@@ -106,6 +107,9 @@ def lib() -> ctypes.CDLL:
     L.rydiff_backward.restype = i32
     L.rydiff_apply_hamiltonian.argtypes = [ctypes.POINTER(RydProblem), vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     L.rydiff_apply_hamiltonian.restype = i32
+    L.rydiff_apply_factor.argtypes = [ctypes.POINTER(RydProblem), vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp,
+                                      ctypes.c_size_t, vp]
+    L.rydiff_apply_factor.restype = i32
     L.rydiff_design_polynomial.argtypes = [dbl, dbl, i32, ctypes.POINTER(i32), vp, vp, ctypes.POINTER(dbl)]
     L.rydiff_design_polynomial.restype = i32
     L.rydiff_set_kernel_variant.argtypes = [i32]

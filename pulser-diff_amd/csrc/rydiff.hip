@@ -32,6 +32,7 @@ using namespace rydiff;
 // ------------------------------------------------------------------------------------------------
 // gradient accumulators are replicated so that concurrent blocks do not serialise on one address
 constexpr int kGradReplicas = 64;
+constexpr int kMaxRemote = 6;  // up to 2^6 GPUs in a state-sharded run
 
 static thread_local std::string g_last_error;
 static int g_kernel_variant = 0;
@@ -74,6 +75,13 @@ struct FactorArgs {
     uint32_t dim;
     double gr, gi, br, bi;  // gamma, beta
     GroupArgs g;
+    // optional: coefficient record passed by value, and contributions of vectors owned by OTHER GPUs (state sharding):
+    //   y += rc_k * remote_k[x]   (the flip terms of the qubits that select the GPU; see pulser-diff_amd/sharded.py)
+    int use_inline;
+    double coef_inline[3 * kMaxGroups];
+    int n_remote;
+    const double2* remote[kMaxRemote];
+    double rc[2 * kMaxRemote];
 };
 
 struct FactorBwdArgs {
@@ -316,11 +324,16 @@ __global__ __launch_bounds__(256) void k_factor_direct(FactorArgs a) {
     if (x >= a.dim) return;
     const size_t boff = size_t(blockIdx.y) * a.dim;
     const double2* __restrict__ xin = a.xin + boff;
-    const double* __restrict__ cf = a.coef + blockIdx.y * a.coef_bstride;
+    const double* __restrict__ cf = a.use_inline ? a.coef_inline : a.coef + blockIdx.y * a.coef_bstride;
     const double d = diag_value(a.udiag, cf, a.g, x);
     const double2 v = xin[x];
     const double dr = a.gr + a.br * d, di = a.gi + a.bi * d;
     double ar = dr * v.x - di * v.y, ai = dr * v.y + di * v.x;
+    for (int k = 0; k < a.n_remote; ++k) {
+        const double2 rv = a.remote[k][boff + x];
+        ar += a.rc[2 * k] * rv.x - a.rc[2 * k + 1] * rv.y;
+        ai += a.rc[2 * k] * rv.y + a.rc[2 * k + 1] * rv.x;
+    }
     for (int q = 0; q < a.g.ga; ++q) {
         double s1r = 0.0, s1i = 0.0, s0r = 0.0, s0i = 0.0;
         uint32_t m = a.g.amask[q];
@@ -1499,11 +1512,13 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
     return RYDIFF_OK;
 }
 
-int rydiff_apply_hamiltonian(const RydProblem* p, const double* c_amp_reim, const double* c_det, const void* x, void* y,
-                             void* workspace, size_t workspace_bytes, void* stream_) {
+int rydiff_apply_factor(const RydProblem* p, const double* c_amp_reim, const double* c_det, const double* gamma_reim,
+                        const double* beta_reim, const void* x, void* y, int n_remote, const void* const* remote,
+                        const double* remote_coef_reim, int reuse_diag, void* workspace, size_t workspace_bytes, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (!x || !y || !workspace) return fail(RYDIFF_EINVAL, "null buffer");
-    // build a plan without time structure: reuse build_plan with a dummy 2-point tsave if none is given
+    if (!x || !y || !workspace || !gamma_reim || !beta_reim) return fail(RYDIFF_EINVAL, "null buffer");
+    if (n_remote < 0 || n_remote > kMaxRemote || (n_remote > 0 && (!remote || !remote_coef_reim)))
+        return fail(RYDIFF_EINVAL, "bad remote vector list");
     RydProblem q = *p;
     double dummy_t[2] = {0.0, 1.0};
     if (q.n_tsave < 2 || !q.tsave) {
@@ -1516,44 +1531,54 @@ int rydiff_apply_hamiltonian(const RydProblem* p, const double* c_amp_reim, cons
     if (!build_plan(&q, rt.pl, err)) return fail(RYDIFF_EINVAL, err);
     Plan& pl = rt.pl;
     fill_group_args(pl, rt.garg);
-    const size_t need = align_up(size_t(std::max(pl.NC, 1)) * sizeof(double)) + align_up(pl.dim * sizeof(double));
+    const size_t need = align_up(pl.dim * sizeof(double));
     if (workspace_bytes < need) return fail(RYDIFF_EWORKSPACE, "workspace too small: need " + std::to_string(need));
-    std::vector<double> rec(std::max(pl.NC, 1), 0.0);
+    FactorArgs fa{};
+    fa.use_inline = 1;
     for (int g = 0; g < pl.ga.n; ++g)
         for (int k = 0; k < pl.Ka; ++k)
             if (pl.ga.members[g] >> k & 1ull) {
-                rec[g] += c_amp_reim[2 * k];
-                rec[pl.ga.n + g] += c_amp_reim[2 * k + 1];
+                fa.coef_inline[g] += c_amp_reim[2 * k];
+                fa.coef_inline[pl.ga.n + g] += c_amp_reim[2 * k + 1];
             }
     for (int g = 0; g < pl.gd.n; ++g)
         for (int k = 0; k < pl.Kd; ++k)
-            if (pl.gd.members[g] >> k & 1ull) rec[2 * pl.ga.n + g] += 2.0 * c_det[k];
-    char* ws = static_cast<char*>(workspace);
-    double* dcoef = reinterpret_cast<double*>(ws);
-    double* udiag = reinterpret_cast<double*>(ws + align_up(size_t(std::max(pl.NC, 1)) * sizeof(double)));
-    HIP_TRY(hipMemcpyAsync(dcoef, rec.data(), rec.size() * sizeof(double), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    if (pl.N > 1) {
-        hipLaunchKernelGGL(k_build_udiag, dim3((pl.dim + 255) / 256), dim3(256), 0, stream, udiag, p->u_pairs, pl.N, uint32_t(pl.dim));
-        LAUNCH_CHECK();
-    } else {
-        HIP_TRY(hipMemsetAsync(udiag, 0, pl.dim * sizeof(double), stream));
+            if (pl.gd.members[g] >> k & 1ull) fa.coef_inline[2 * pl.ga.n + g] += 2.0 * c_det[k];
+    double* udiag = static_cast<double*>(workspace);
+    if (!reuse_diag) {
+        if (pl.N > 1) {
+            hipLaunchKernelGGL(k_build_udiag, dim3((pl.dim + 255) / 256), dim3(256), 0, stream, udiag, p->u_pairs, pl.N, uint32_t(pl.dim));
+            LAUNCH_CHECK();
+        } else {
+            HIP_TRY(hipMemsetAsync(udiag, 0, pl.dim * sizeof(double), stream));
+        }
     }
-    FactorArgs fa{};
     fa.xin = static_cast<const double2*>(x);
     fa.xout = static_cast<double2*>(y);
     fa.udiag = udiag;
-    fa.coef = dcoef;
+    fa.coef = nullptr;
     fa.coef_bstride = 0;
     fa.dim = uint32_t(pl.dim);
-    fa.gr = 0.0;
-    fa.gi = 0.0;
-    fa.br = 1.0;
-    fa.bi = 0.0;
+    fa.gr = gamma_reim[0];
+    fa.gi = gamma_reim[1];
+    fa.br = beta_reim[0];
+    fa.bi = beta_reim[1];
     fa.g = rt.garg;
+    fa.n_remote = n_remote;
+    for (int k = 0; k < n_remote; ++k) {
+        fa.remote[k] = static_cast<const double2*>(remote[k]);
+        fa.rc[2 * k] = remote_coef_reim[2 * k];
+        fa.rc[2 * k + 1] = remote_coef_reim[2 * k + 1];
+    }
     hipLaunchKernelGGL(k_factor_direct, dim3(unsigned((pl.dim + 255) / 256), pl.B), dim3(256), 0, stream, fa);
     LAUNCH_CHECK();
     return RYDIFF_OK;
+}
+
+int rydiff_apply_hamiltonian(const RydProblem* p, const double* c_amp_reim, const double* c_det, const void* x, void* y,
+                             void* workspace, size_t workspace_bytes, void* stream_) {
+    const double zero[2] = {0.0, 0.0}, one[2] = {1.0, 0.0};
+    return rydiff_apply_factor(p, c_amp_reim, c_det, zero, one, x, y, 0, nullptr, nullptr, 0, workspace, workspace_bytes, stream_);
 }
 
 }  // extern "C"
