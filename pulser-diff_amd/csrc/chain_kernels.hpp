@@ -50,6 +50,10 @@ struct ChainArgs {
     uint32_t sta_mask[kMaxGroups];     // per flip group: TILE-bit mask handled by the start stage
     uint32_t dmask[kMaxGroups];        // detuning groups: amplitude-INDEX masks
     int dcnt[kMaxGroups];
+    // single-pass mode (layout A only, has_p = 0): the flips of the index bits OUTSIDE the tile are taken from the
+    // partner tiles in global memory (L2 / Infinity Cache) during the start stage, so q_out is the complete factor output
+    uint32_t hi_mask[kMaxGroups];      // per flip group: amplitude-INDEX bits >= LT
+    int xcd_swizzle;                   // map consecutive tiles of one 2^(N-3) slab to workgroups that share an XCD (blockIdx % 8)
     // backward (adjoint) mode only: u/p/v/q are cotangents, gamma/beta above are already conjugated
     const double2* x_fin;   // input of the factor being finished (own elements only)
     const double2* x_sta;   // input of the factor being started
@@ -134,7 +138,10 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) double2 tile[];
     double* red = reinterpret_cast<double*>(tile + (size_t(1) << LT));  // NT/64 doubles behind the tile (BWD only)
     const unsigned tid = threadIdx.x;
-    const unsigned t = blockIdx.x;
+    // XCD-aware tile order (speed only): workgroups b and b+8 share an XCD's L2, so give each XCD a contiguous block of
+    // tiles — the partner tiles of the low tile-index bits are then hits in that L2
+    const unsigned ntile = gridDim.x;
+    const unsigned t = a.xcd_swizzle ? ((blockIdx.x & 7u) * (ntile >> 3) + (blockIdx.x >> 3)) : blockIdx.x;
     const size_t boff = size_t(blockIdx.y) * a.dim;
     const unsigned lomask = (1u << a.lo) - 1u;
     const int midlow = a.hs - a.lo;
@@ -281,13 +288,31 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     }
     for (int g = 0; g < a.ga; ++g) {
         const uint32_t mask = a.sta_mask[g];
-        if (!mask) continue;
+        if (!mask && !a.hi_mask[g]) continue;
         double2 ts[R], ds[R];
 #ifndef RYDIFF_ABLATE_COMPUTE
         partner_sums<LT, LGT, CPLX || BWD>(tile, acc, mask, tid, ts, ds);
 #else
         for (int r = 0; r < R; ++r) { ts[r] = acc[r]; ds[r] = acc[r]; }
 #endif
+        {   // single-pass mode: partner tiles for the index bits outside this tile (coalesced 16-B loads, same offsets)
+            uint32_t hm = a.hi_mask[g];
+            while (hm) {
+                const uint32_t bit = hm & (0u - hm);
+                hm ^= bit;
+                const double sgn = (xbase & bit) ? 1.0 : -1.0;  // own bit of this whole tile
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const double2 pv = a.u[boff + (xg[r] ^ bit)];
+                    ts[r].x += pv.x;
+                    ts[r].y += pv.y;
+                    if (CPLX || BWD) {
+                        ds[r].x = fma(sgn, pv.x, ds[r].x);
+                        ds[r].y = fma(sgn, pv.y, ds[r].y);
+                    }
+                }
+            }
+        }
         const double cr = cf[g], ci = cf[a.ga + g];
         const double k1r = a.sb_r * cr, k1i = a.sb_i * cr;
         const double k2r = -a.sb_i * ci, k2i = a.sb_r * ci;

@@ -732,7 +732,7 @@ int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_
     int rc = finish_runtime(rt, lo, hi);
     if (rc) return rc;
     Plan& pl = rt.pl;
-    if (need_tape == 2 && !(pl.N > kTileBitsHost && pl.N <= 2 * kTileBitsHost && g_kernel_variant != 1)) need_tape = 1;  // full tape only with chained passes
+    if (need_tape == 2 && !(pl.N > kTileBitsHost && pl.N <= 2 * kTileBitsHost && g_kernel_variant != 1 && g_kernel_variant != 5)) need_tape = 1;  // full tape only with chained passes
     const size_t need = carve(pl, need_tape, need_backward, std::max(rt.max_step_factors - 1, 1), rt.total_factors);
     if (workspace_bytes < need)
         return fail(RYDIFF_EWORKSPACE, "workspace too small: need " + std::to_string(need) + " bytes, got " + std::to_string(workspace_bytes));
@@ -828,8 +828,12 @@ void build_step_chain(const Runtime& rt, int k, std::vector<ChainItem>& chain) {
     }
 }
 
+int launch_single_fwd(const Runtime& rt, char* ws, const double2* xin, double2* xout, int stage, const FactorScalars& s, hipStream_t stream);
+bool single_pass_enabled(const Runtime& rt);
+
 int launch_factor(const Runtime& rt, char* ws, const double2* xin, double2* xout, int stage, const FactorScalars& s, hipStream_t stream) {
     const Plan& pl = rt.pl;
+    if (single_pass_enabled(rt)) return launch_single_fwd(rt, ws, xin, xout, stage, s, stream);
     FactorArgs fa{};
     fa.xin = xin;
     fa.xout = xout;
@@ -881,7 +885,7 @@ uint32_t to_tile_mask(const LayoutDesc& d, uint32_t index_mask) {
 
 bool chain_enabled(const Runtime& rt) {
     const int N = rt.pl.N;
-    if (g_kernel_variant == 1) return false;
+    if (g_kernel_variant == 1 || g_kernel_variant == 5) return false;
     return N > kTileBits && N <= 2 * kTileBits;
 }
 
@@ -901,6 +905,7 @@ struct ChainStep {
     const double2* x_sta = nullptr;
     double cb_fin_r = 0, cb_fin_i = 0, cb_sta_r = 0, cb_sta_i = 0;
     double* wtot = nullptr;
+    bool single = false;  // single-pass mode: complete factor in one launch (partner tiles from L2 / Infinity Cache)
     // fused expectation (forward)
     const double* obs = nullptr;
     double* expect_slot = nullptr;
@@ -967,7 +972,9 @@ int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, hipStream_t s
     for (int g = 0; g < pl.ga.n; ++g) {
         ca.fin_mask[g] = to_tile_mask(X, pl.ga.amp_index_mask[g] & ~prev_bits);
         ca.sta_mask[g] = to_tile_mask(X, pl.ga.amp_index_mask[g]);
+        ca.hi_mask[g] = cs.single ? (pl.ga.amp_index_mask[g] & ~X.bits) : 0u;
     }
+    ca.xcd_swizzle = (cs.single && (pl.dim >> kTileBits) >= 64 && ((pl.dim >> kTileBits) % 8) == 0) ? 1 : 0;
     for (int g = 0; g < pl.gd.n; ++g) {
         ca.dmask[g] = pl.gd.amp_index_mask[g];
         ca.dcnt[g] = pl.gd.count[g];
@@ -1040,6 +1047,36 @@ int run_chain(const Runtime& rt, char* ws, const std::vector<ChainItem>& items, 
         }
     }
     return RYDIFF_OK;
+}
+
+bool single_pass_enabled(const Runtime& rt) {
+    const int N = rt.pl.N;
+    if (g_kernel_variant == 5) return N > kTileBits && N <= 24;
+    return false;
+}
+
+// one launch per factor: q_out = (gamma + beta H) u, complete (single-pass mode of k_chain)
+int launch_single(const Runtime& rt, char* ws, const double2* xin, double2* xout, const ChainItem& it, hipStream_t stream,
+                  const double* obs = nullptr, double* expect_slot = nullptr) {
+    (void)obs; (void)expect_slot;
+    ChainStep cs{};
+    cs.single = true;
+    cs.layout = 0;
+    cs.prev_layout = -1;
+    cs.u = xin;
+    cs.has_p = 0;
+    cs.has_q = 1;
+    cs.write_v = 0;
+    cs.q_out = xout;
+    cs.fin_stage = -1;
+    cs.sta_stage = it.stage;
+    cs.sta = it.s;
+    return launch_chain(rt, ws, cs, stream);
+}
+
+int launch_single_fwd(const Runtime& rt, char* ws, const double2* xin, double2* xout, int stage, const FactorScalars& s, hipStream_t stream) {
+    ChainItem it{stage, s};
+    return launch_single(rt, ws, xin, xout, it, stream);
 }
 
 // Adjoint sweep of one tsave interval as a chain.  `items` are the interval's forward factors (in forward order),
@@ -1145,7 +1182,8 @@ const char* rydiff_version(void) { return "rydiff 0.1 (gfx950)"; }
 
 int rydiff_set_kernel_variant(int variant) {
     // 0 auto | 1 direct | 2 chained tiles, 512 threads | 3 chained tiles, 256 threads | 4 chained tiles, 1024 threads
-    if (variant < 0 || variant > 4) return fail(RYDIFF_EINVAL, "kernel variant must be 0..4");
+    // 5 single-pass LDS tiles with partner-tile loads (forward / recompute passes; adjoint stays direct)
+    if (variant < 0 || variant > 5) return fail(RYDIFF_EINVAL, "kernel variant must be 0..5");
     g_kernel_variant = variant;
     g_chain_lgt = variant == 3 ? 8 : (variant == 4 ? 10 : 9);
     return RYDIFF_OK;
@@ -1180,7 +1218,7 @@ int rydiff_plan(const RydProblem* p, int need_tape, int need_backward, void* scr
     rc = finish_runtime(rt, lo, hi);
     if (rc) return rc;
     int tm = need_tape;
-    if (tm == 2 && !(rt.pl.N > kTileBitsHost && rt.pl.N <= 2 * kTileBitsHost && g_kernel_variant != 1)) tm = 1;
+    if (tm == 2 && !(rt.pl.N > kTileBitsHost && rt.pl.N <= 2 * kTileBitsHost && g_kernel_variant != 1 && g_kernel_variant != 5)) tm = 1;
     const size_t ws = carve(rt.pl, tm, need_backward != 0, std::max(rt.max_step_factors - 1, 1), rt.total_factors);
     fill_info(rt, lo, hi, ws, info);
     return RYDIFF_OK;

@@ -28,6 +28,47 @@ def _t(v: Any) -> Tensor:
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# sequence variables (pulser.parametrized restated for the subset QuantumModel needs, model.py:208-299)
+# ---------------------------------------------------------------------------------------------------------------
+class Variable:
+    """A named placeholder declared with ``Sequence.declare_variable``; resolved by ``Sequence.build(**values)``."""
+
+    def __init__(self, name: str, size: int = 1):
+        self.name, self.size = name, int(size)
+
+    def __getitem__(self, i: int) -> "VariableItem":
+        return VariableItem(self, i)
+
+    def __repr__(self) -> str:
+        return f"Variable({self.name!r}, size={self.size})"
+
+
+class VariableItem:
+    def __init__(self, var: Variable, index: int):
+        self.var, self.index = var, index
+
+    @property
+    def name(self) -> str:
+        return self.var.name
+
+
+def is_param(v: Any) -> bool:
+    return isinstance(v, (Variable, VariableItem))
+
+
+def resolve(v: Any, values: dict) -> Any:
+    """Substitute a declared variable by its value (a tensor keeps its autograd history)."""
+    if isinstance(v, VariableItem):
+        val = values[v.var.name]
+        val = val if isinstance(val, Tensor) else torch.as_tensor(val)
+        return val.reshape(-1)[v.index]
+    if isinstance(v, Variable):
+        val = values[v.name]
+        return val if isinstance(val, Tensor) else torch.as_tensor(val)
+    return v
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # device / register
 # ---------------------------------------------------------------------------------------------------------------
 @dataclass(frozen=True)
@@ -90,11 +131,26 @@ class Register:
 # waveforms (per-ns samples in rad/us)
 # ---------------------------------------------------------------------------------------------------------------
 class Waveform:
-    def __init__(self, duration: int):
-        duration = int(duration)
-        if duration <= 0:
-            raise ValueError("A waveform must have a positive duration.")
+    def __init__(self, duration):
+        self._duration_param = duration if is_param(duration) else None
+        if self._duration_param is None:
+            duration = int(duration)
+            if duration <= 0:
+                raise ValueError("A waveform must have a positive duration.")
         self.duration = duration
+
+    def is_parametrized(self) -> bool:
+        return any(is_param(v) for v in vars(self).values())
+
+    def build(self, values: dict) -> "Waveform":
+        """Concrete copy with every declared variable substituted (durations are given in ns)."""
+        kw = {k: resolve(v, values) for k, v in self._ctor_args().items()}
+        if "duration" in kw and isinstance(kw["duration"], Tensor):
+            kw["duration"] = int(kw["duration"])
+        return type(self)(**kw)
+
+    def _ctor_args(self) -> dict:  # pragma: no cover - abstract
+        raise NotImplementedError
 
     @property
     def samples(self) -> Tensor:  # pragma: no cover - abstract
@@ -106,9 +162,12 @@ class Waveform:
 
 
 class ConstantWaveform(Waveform):
-    def __init__(self, duration: int, value):
+    def __init__(self, duration, value):
         super().__init__(duration)
-        self.value = _t(value).reshape(())
+        self.value = value if is_param(value) else _t(value).reshape(())
+
+    def _ctor_args(self) -> dict:
+        return {"duration": self.duration, "value": self.value}
 
     @property
     def samples(self) -> Tensor:
@@ -116,9 +175,13 @@ class ConstantWaveform(Waveform):
 
 
 class RampWaveform(Waveform):
-    def __init__(self, duration: int, start, stop):
+    def __init__(self, duration, start, stop):
         super().__init__(duration)
-        self.start, self.stop = _t(start).reshape(()), _t(stop).reshape(())
+        self.start = start if is_param(start) else _t(start).reshape(())
+        self.stop = stop if is_param(stop) else _t(stop).reshape(())
+
+    def _ctor_args(self) -> dict:
+        return {"duration": self.duration, "start": self.start, "stop": self.stop}
 
     @property
     def samples(self) -> Tensor:
@@ -127,9 +190,12 @@ class RampWaveform(Waveform):
 
 
 class BlackmanWaveform(Waveform):
-    def __init__(self, duration: int, area):
+    def __init__(self, duration, area):
         super().__init__(duration)
-        self.area = _t(area).reshape(())
+        self.area = area if is_param(area) else _t(area).reshape(())
+
+    def _ctor_args(self) -> dict:
+        return {"duration": self.duration, "area": self.area}
 
     @property
     def samples(self) -> Tensor:
@@ -140,9 +206,12 @@ class BlackmanWaveform(Waveform):
 class KaiserWaveform(Waveform):
     """Kaiser window normalised to `area` (beta defaults to pulser's 14; NOT pinned by any stored output)."""
 
-    def __init__(self, duration: int, area, beta: float = 14.0):
+    def __init__(self, duration, area, beta: float = 14.0):
         super().__init__(duration)
-        self.area, self.beta = _t(area).reshape(()), float(beta)
+        self.area, self.beta = (area if is_param(area) else _t(area).reshape(())), float(beta)
+
+    def _ctor_args(self) -> dict:
+        return {"duration": self.duration, "area": self.area, "beta": self.beta}
 
     @property
     def samples(self) -> Tensor:
@@ -152,9 +221,16 @@ class KaiserWaveform(Waveform):
 
 class CustomWaveform(Waveform):
     def __init__(self, samples):
+        if isinstance(samples, Variable):
+            super().__init__(samples.size)
+            self._samples = samples
+            return
         s = _t(samples).reshape(-1)
         super().__init__(s.numel())
         self._samples = s
+
+    def _ctor_args(self) -> dict:
+        return {"samples": self._samples}
 
     @property
     def samples(self) -> Tensor:
@@ -169,13 +245,23 @@ class Pulse:
     post_phase_shift: Any = 0.0
 
     def __post_init__(self):
-        if self.amplitude.duration != self.detuning.duration:
+        if not (is_param(self.amplitude.duration) or is_param(self.detuning.duration)) \
+                and self.amplitude.duration != self.detuning.duration:
             raise ValueError("The duration of detuning and amplitude waveforms must match.")
-        self.phase = _t(self.phase).reshape(())
+        if not is_param(self.phase):
+            ph = _t(self.phase)
+            self.phase = ph.reshape(()) if ph.numel() == 1 else ph.reshape(-1)  # scalar, or one value per sample
 
     @property
     def duration(self) -> int:
         return self.amplitude.duration
+
+    def is_parametrized(self) -> bool:
+        return self.amplitude.is_parametrized() or self.detuning.is_parametrized() or is_param(self.phase)
+
+    def build(self, values: dict) -> "Pulse":
+        return Pulse(self.amplitude.build(values), self.detuning.build(values), resolve(self.phase, values),
+                     self.post_phase_shift)
 
     @classmethod
     def ConstantPulse(cls, duration: int, amplitude, detuning, phase, post_phase_shift=0.0) -> "Pulse":
@@ -297,6 +383,34 @@ class Sequence:
         self._schedule: dict[str, list] = {}
         self._targets: dict[str, frozenset] = {}
         self._slm_mask_targets: set = set()
+        self._variables: dict[str, Variable] = {}
+
+    @property
+    def declared_variables(self) -> dict:
+        return dict(self._variables)
+
+    def declare_variable(self, name: str, size: int = 1, dtype=float):
+        """pulser Sequence.declare_variable: a scalar variable is returned as its single item."""
+        if name in self._variables:
+            raise ValueError("Name for variable is already being used.")
+        var = Variable(name, size)
+        self._variables[name] = var
+        return var[0] if size == 1 else var
+
+    def build(self, **values) -> "Sequence":
+        """Concrete sequence with every declared variable substituted (pulser Sequence.build)."""
+        missing = set(self._variables) - set(values)
+        if missing:
+            raise TypeError(f"Did not receive values for variables: {sorted(missing)}")
+        out = Sequence(self.register, self.device)
+        out._channels = dict(self._channels)
+        out._targets = dict(self._targets)
+        out._schedule = {ch: [(kind, obj.build(values) if kind == "pulse" else obj, tg) for kind, obj, tg in items]
+                         for ch, items in self._schedule.items()}
+        return out
+
+    def _set_register(self, register: "Register") -> None:
+        self.register = register
 
     @property
     def declared_channels(self) -> dict:
@@ -341,7 +455,7 @@ class Sequence:
                    default=0)
 
     def is_parametrized(self) -> bool:
-        return False
+        return any(kind == "pulse" and obj.is_parametrized() for items in self._schedule.values() for kind, obj, _ in items)
 
     def is_register_mappable(self) -> bool:
         return False

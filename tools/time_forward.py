@@ -4,6 +4,9 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch
 from pulser_diff_amd.solver import ProblemSpec, SolverType, evolve
+from pulser_diff_amd import _native
+import os
+_native.set_kernel_variant(int(os.environ.get('RYDIFF_VARIANT', '0')))
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 100
