@@ -91,7 +91,8 @@ class QuantumModel(Module):
         total = 0
         for _, pulse, _ in self._pulse_items():
             d = pulse.amplitude.duration
-            total += int(float(pl.resolve(d, values)) * 1000) if pl.is_param(d) else int(d)
+            # like the reference, the product is formed in the parameter's own dtype (float32 leaves: 0.19*1000 -> 190)
+            total += int((pl.resolve(d, values).detach() * 1000).item()) if pl.is_param(d) else int(d)
         return total + 5
 
     def _pulse_items(self):
