@@ -592,6 +592,7 @@ __global__ void k_scatter_grads(ScatterArgs a) {
 }
 
 #include "chain_kernels.hpp"
+#include "chain2_kernels.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -935,8 +936,12 @@ int launch_chain_l(const ChainArgs& ca, unsigned tiles, int B, bool cplx, bool b
 
 int g_chain_lgt = 9;  // log2(threads per tile workgroup): 512 threads, 8 amplitudes per thread
 
+int launch_chain2(const Runtime& rt, char* ws, const ChainStep& cs, hipStream_t stream);
+bool chain2_enabled(const Runtime& rt);
+
 int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, hipStream_t stream) {
     const Plan& pl = rt.pl;
+    if (!cs.single && chain2_enabled(rt)) return launch_chain2(rt, ws, cs, stream);
     const LayoutDesc X = chain_layout(pl.N, cs.layout);
     ChainArgs ca{};
     ca.u = cs.u;
@@ -1007,6 +1012,107 @@ int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, hipStream_t s
         case 10: return launch_chain_l<10>(ca, tiles, pl.B, cplx, cs.bwd, stream);
         default: return launch_chain_l<9>(ca, tiles, pl.B, cplx, cs.bwd, stream);
     }
+}
+
+// ---- sub-tile pipelined variant (chain2_kernels.hpp): 13 <= N <= 22 -------------------------------------------------
+bool chain2_enabled(const Runtime& rt) {
+    const int N = rt.pl.N;
+    if (!(g_kernel_variant == 0 || g_kernel_variant == 6)) return false;
+    return N > kTileBits && N <= 22;
+}
+
+template <int LGT, bool CPLX, bool BWD>
+int launch_chain2_t(const Chain2Args& ca, unsigned tiles, int B, hipStream_t stream) {
+    static bool attr_set = false;
+    const size_t lds = (size_t(2) << 11) * sizeof(double2) + 256;
+    auto kern = k_chain2<LGT, CPLX, BWD>;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles, B), dim3(1 << LGT), lds, stream, ca);
+    LAUNCH_CHECK();
+    return RYDIFF_OK;
+}
+
+int launch_chain2(const Runtime& rt, char* ws, const ChainStep& cs, hipStream_t stream) {
+    const Plan& pl = rt.pl;
+    const LayoutDesc X = chain_layout(pl.N, cs.layout);
+    const int lo_b = 2 * kTileBits - pl.N;
+    auto excluded = [&](int layout) { return layout == 0 ? lo_b - 1 : lo_b - 2; };  // index bit excluded from the local flips
+    Chain2Args ca{};
+    ca.u = cs.u;
+    ca.p = cs.p;
+    ca.v_out = cs.v_out;
+    ca.q_out = cs.q_out;
+    {
+        const size_t per_layout = 4096 + size_t(pl.dim >> kTileBits) * 16;
+        const double* split = reinterpret_cast<const double*>(ws + pl.off_split) + size_t(cs.layout) * per_layout;
+        ca.utt = split;
+        ca.vr = split + 4096;
+    }
+    const double* coef = reinterpret_cast<const double*>(ws + pl.off_coef);
+    ca.coef_fin = coef + size_t(std::max(cs.fin_stage, 0)) * pl.NC;
+    ca.coef_sta = coef + size_t(std::max(cs.sta_stage, 0)) * pl.NC;
+    ca.coef_bstride = pl.Bc > 1 ? long(pl.stages.size()) * pl.NC : 0;
+    ca.fb_r = cs.fin.br;
+    ca.fb_i = cs.fin.bi;
+    ca.sg_r = cs.sta.gr;
+    ca.sg_i = cs.sta.gi;
+    ca.sb_r = cs.sta.br;
+    ca.sb_i = cs.sta.bi;
+    ca.lo = X.lo;
+    ca.hs = X.hs;
+    ca.hb = X.hb;
+    ca.sub_bit = excluded(cs.layout);  // both layouts keep their low index bits at the same super-tile positions
+    ca.dim = uint32_t(pl.dim);
+    ca.has_p = cs.has_p;
+    ca.has_q = cs.has_q;
+    ca.write_v = cs.write_v;
+    ca.ga = pl.ga.n;
+    ca.gd = pl.gd.n;
+    uint32_t prev_cov = 0;
+    if (cs.prev_layout >= 0) prev_cov = chain_layout(pl.N, cs.prev_layout).bits & ~(1u << excluded(cs.prev_layout));
+    for (int g = 0; g < pl.ga.n; ++g) {
+        uint32_t fm = 0, sm = 0;
+        for (int c = 0; c < 11; ++c) {
+            const int tb = c < ca.sub_bit ? c : c + 1;
+            const int gb = tb < X.lo ? tb : X.hs + (tb - X.lo);
+            if (pl.ga.amp_index_mask[g] >> gb & 1u) {
+                sm |= 1u << c;
+                if (!(prev_cov >> gb & 1u)) fm |= 1u << c;
+            }
+        }
+        ca.fin_mask[g] = fm;
+        ca.sta_mask[g] = sm;
+    }
+    for (int g = 0; g < pl.gd.n; ++g) {
+        ca.dmask[g] = pl.gd.amp_index_mask[g];
+        ca.dcnt[g] = pl.gd.count[g];
+    }
+    ca.obs = cs.obs;
+    ca.expect_slot = cs.expect_slot;
+    ca.n_obs = cs.n_obs;
+    ca.exp_ostride = cs.exp_ostride;
+    if (cs.bwd) {
+        double* ge = reinterpret_cast<double*>(ws + pl.off_ge);
+        const long ge_rec = long(kGradReplicas) * (pl.NC + 1);
+        ca.x_fin = cs.x_fin;
+        ca.x_sta = cs.x_sta;
+        ca.ge_fin = ge + size_t(std::max(cs.fin_stage, 0)) * ge_rec;
+        ca.ge_sta = ge + size_t(std::max(cs.sta_stage, 0)) * ge_rec;
+        ca.ge_bstride = pl.Bc > 1 ? long(pl.stages.size()) * ge_rec : 0;
+        ca.ge_rstride = pl.NC + 1;
+        ca.cb_fin_r = cs.cb_fin_r;
+        ca.cb_fin_i = cs.cb_fin_i;
+        ca.cb_sta_r = cs.cb_sta_r;
+        ca.cb_sta_i = cs.cb_sta_i;
+        ca.wtot = cs.wtot;
+    }
+    const unsigned tiles = unsigned(pl.dim >> kTileBits);
+    const bool cplx = (rt.flags & 1) != 0;
+    if (cs.bwd) return launch_chain2_t<9, true, true>(ca, tiles, pl.B, stream);
+    return cplx ? launch_chain2_t<10, true, false>(ca, tiles, pl.B, stream) : launch_chain2_t<10, false, false>(ca, tiles, pl.B, stream);
 }
 
 // Run `items` (factors, in order) as a chain starting from the complete vector `start`.
@@ -1183,7 +1289,8 @@ const char* rydiff_version(void) { return "rydiff 0.1 (gfx950)"; }
 int rydiff_set_kernel_variant(int variant) {
     // 0 auto | 1 direct | 2 chained tiles, 512 threads | 3 chained tiles, 256 threads | 4 chained tiles, 1024 threads
     // 5 single-pass LDS tiles with partner-tile loads (forward / recompute passes; adjoint stays direct)
-    if (variant < 0 || variant > 5) return fail(RYDIFF_EINVAL, "kernel variant must be 0..5");
+    // 6 chained tiles with sub-tile pipelining (what auto picks for 13 <= N <= 22)
+    if (variant < 0 || variant > 6) return fail(RYDIFF_EINVAL, "kernel variant must be 0..6");
     g_kernel_variant = variant;
     g_chain_lgt = variant == 3 ? 8 : (variant == 4 ? 10 : 9);
     return RYDIFF_OK;
