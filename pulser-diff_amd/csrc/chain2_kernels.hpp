@@ -72,27 +72,33 @@ __global__ __launch_bounds__(1 << LGT) void k_chain2(Chain2Args a) {
     double dg[2][R];
     unsigned xg[2][R];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 2; ++k) {  // sub-tile 0's loads are issued (and hence retire: vmcnt is in order) before sub-tile 1's
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const unsigned j = unsigned(r) * NT + tid;                                   // sub-tile-local index
             const unsigned i = ((j & ~below) << 1) | (unsigned(k) << sb) | (j & below);   // super-tile index
             xg[k][r] = xbase | (i & lomask) | ((i >> a.lo) << a.hs);
             uu[k][r] = a.u[boff + xg[k][r]];
-            if (a.has_q) dg[k][r] = a.utt[i];
         }
-    }
-    if (a.has_p) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
+        if (a.has_p) {
 #pragma unroll
             for (int r = 0; r < R; ++r) pp[k][r] = a.p[boff + xg[k][r]];
-    }
-    if (BWD && a.has_p) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
+        }
+        if (BWD && a.has_p) {
 #pragma unroll
             for (int r = 0; r < R; ++r) xf[k][r] = a.x_fin[boff + xg[k][r]];
+        }
+        if (a.has_q) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const unsigned j = unsigned(r) * NT + tid;
+#ifndef RYDIFF_ABLATE_DIAG
+                dg[k][r] = a.utt[((j & ~below) << 1) | (unsigned(k) << sb) | (j & below)];
+#else
+                dg[k][r] = 0.0;
+#endif
+            }
+        }
     }
     // interaction diagonal: remote part + cross terms of the super-tile bits (n = 1 - bit)
     double vloc[12];
@@ -128,7 +134,11 @@ __global__ __launch_bounds__(1 << LGT) void k_chain2(Chain2Args a) {
                 const uint32_t mask = a.fin_mask[g];
                 if (!mask) continue;
                 double2 ts[R], ds[R];
+#ifndef RYDIFF_ABLATE_COMPUTE
                 partner_sums<LS, LGT, CPLX || BWD>(tile, uu[k], mask, tid, ts, ds);
+#else
+                for (int r = 0; r < R; ++r) { ts[r] = uu[k][r]; ds[r] = uu[k][r]; }
+#endif
                 const double cr = cff[g], ci = cff[a.ga + g];
                 const double k1r = a.fb_r * cr, k1i = a.fb_i * cr, k2r = -a.fb_i * ci, k2i = a.fb_r * ci;
 #pragma unroll
@@ -214,7 +224,11 @@ __global__ __launch_bounds__(1 << LGT) void k_chain2(Chain2Args a) {
             const uint32_t mask = a.sta_mask[g];
             if (!mask) continue;
             double2 ts[R], ds[R];
+#ifndef RYDIFF_ABLATE_COMPUTE
             partner_sums<LS, LGT, CPLX || BWD>(tile, acc, mask, tid, ts, ds);
+#else
+            for (int r = 0; r < R; ++r) { ts[r] = acc[r]; ds[r] = acc[r]; }
+#endif
             const double cr = cfs[g], ci = cfs[a.ga + g];
             const double k1r = a.sb_r * cr, k1i = a.sb_i * cr, k2r = -a.sb_i * ci, k2i = a.sb_r * ci;
 #pragma unroll

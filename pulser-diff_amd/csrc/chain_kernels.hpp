@@ -173,9 +173,11 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
 #pragma unroll
         for (int r = 0; r < R; ++r) xf[r] = a.x_fin[boff + xg[r]];
     }
+#ifndef RYDIFF_ABLATE_SYNC
 #pragma unroll
     for (int r = 0; r < R; ++r) tile[unsigned(r) * NT + tid] = uu[r];
     __syncthreads();
+#endif
     double* ge_fin = nullptr;
     double* ge_sta = nullptr;
     if (BWD) {
@@ -195,7 +197,11 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
 #else
             for (int r = 0; r < R; ++r) { ts[r] = uu[r]; ds[r] = uu[r]; }
 #endif
+#ifdef RYDIFF_ABLATE_COEF
+            const double cr = a.sg_r, ci = a.sg_i;
+#else
             const double cr = cf[g], ci = cf[a.ga + g];
+#endif
             // c*s1 + conj(c)*s0 = cr*(s1+s0) + i*ci*(s1-s0);  k1 = beta*cr, k2 = beta*i*ci
             const double k1r = a.fb_r * cr, k1i = a.fb_i * cr;
             const double k2r = -a.fb_i * ci, k2i = a.fb_r * ci;
@@ -244,18 +250,26 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     }
     if (!a.has_q) return;
 
+#ifndef RYDIFF_ABLATE_SYNC
     __syncthreads();  // all partner reads of u are done
 #pragma unroll
     for (int r = 0; r < R; ++r) tile[unsigned(r) * NT + tid] = acc[r];
     __syncthreads();
+#endif
 
     const double* __restrict__ cf = a.coef_sta + blockIdx.y * a.coef_bstride;
     // interaction diagonal: remote part of this tile + cross terms of the tile bits that are in |r> (n = 1 - bit)
     double vloc[LT];
     const double* __restrict__ vrow = a.vr + size_t(t) * 16;
+#ifdef RYDIFF_ABLATE_COEF
+    for (int b2 = 0; b2 < LT; ++b2) vloc[b2] = a.sb_r;
+    double dlane = a.sb_i;
+    (void)vrow;
+#else
 #pragma unroll
     for (int b2 = 0; b2 < LT; ++b2) vloc[b2] = vrow[b2];
     double dlane = vrow[LT];
+#endif
 #pragma unroll
     for (int b2 = 0; b2 < LGT; ++b2)
         if (!(tid >> b2 & 1u)) dlane += vloc[b2];
@@ -313,7 +327,11 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
                 }
             }
         }
+#ifdef RYDIFF_ABLATE_COEF
+        const double cr = a.sg_r, ci = a.sg_i;
+#else
         const double cr = cf[g], ci = cf[a.ga + g];
+#endif
         const double k1r = a.sb_r * cr, k1i = a.sb_i * cr;
         const double k2r = -a.sb_i * ci, k2i = a.sb_r * ci;
 #pragma unroll
