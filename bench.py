@@ -197,7 +197,7 @@ def main() -> None:
                    "parallelism": f"trajectory-sharded x{world}", "matvecs_per_step_fwd": n_mv},
         "forward_only_time_steps_per_s": fwd_steps_per_s,
         "loss": float(loss),
-        "roofline": {"bound": "hbm", "kernel": "k_factor (matrix-free y = gamma*x + beta*H x)",
+        "roofline": {"bound": "hbm", "kernel": "k_chain (one factor pass y = gamma*x + beta*H x of the product-form propagator)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": launch_us,
                      "algorithmic_bytes_per_launch": alg_bytes, "launches": total_factors},

@@ -6,8 +6,9 @@ matrix-exponential-on-vector, expectation values and the adjoint gradient sweep 
 behind the C ABI in ``include/rydiff.h``.
 """
 from pulser_diff_amd.backend import TorchEmulator  # noqa: F401
+from pulser_diff_amd.model import QuantumModel  # noqa: F401
 from pulser_diff_amd.simconfig import SimConfig  # noqa: F401
 from pulser_diff_amd.solver import SolverType  # noqa: F401
 from pulser_diff_amd.utils import DiagonalObservable  # noqa: F401
 
-__all__ = ["TorchEmulator", "SimConfig", "SolverType", "DiagonalObservable"]
+__all__ = ["TorchEmulator", "SimConfig", "SolverType", "DiagonalObservable", "QuantumModel"]
