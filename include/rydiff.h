@@ -77,8 +77,7 @@ typedef struct RydProblem {
     const double* tsave;   /* HOST float64 [n_tsave], strictly increasing, in us */
 
     int32_t solver;        /* RYDIFF_SOLVER_* */
-    double tol;            /* KRYLOV_SE: truncation target per exponential (<=0: default min(1e-12, 1e-9/#steps));
-                              DP5_SE: target accuracy of the continuous-time solution (<=0: default 1e-9) */
+    double tol;            /* per-exponential truncation target (<=0: default 1e-13) */
 
     int32_t n_obs;         /* diagonal observables evaluated at every tsave (utils.py:79-81 for diagonal O) */
     const double* obs_diag;/* DEVICE float64 [n_obs][2^N] */

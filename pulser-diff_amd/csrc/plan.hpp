@@ -149,8 +149,7 @@ inline bool build_plan(const RydProblem* p, Plan& pl, std::string& err) {
     pl.dt = p->dt;
     pl.solver = p->solver;
     if (p->solver == RYDIFF_SOLVER_KRYLOV_SE) {
-        // default: keep the ACCUMULATED truncation error of the whole run below 1e-9 (parity bar: 1e-8)
-        pl.tol = (p->tol > 0.0) ? p->tol : std::min(1e-12, std::max(1e-9 / double(p->n_tsave - 1), 1e-14));
+        pl.tol = (p->tol > 0.0) ? p->tol : 1e-13;
     } else {
         // continuous-time solver: `tol` is the target accuracy of the solution; the exponentials are kept well below it
         pl.ode_tol = (p->tol > 0.0) ? p->tol : 1e-9;
