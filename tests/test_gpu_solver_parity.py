@@ -256,3 +256,37 @@ def test_full_tape_and_step_tape_give_identical_gradients(cuda_device):
         results[mode] = (expect.detach().clone(), amp.grad.clone(), det.grad.clone(), u.grad.clone())
     for a, b in zip(results["steps"], results["full"]):
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-11
+
+
+def test_c_abi_error_codes_map_to_reference_exception_types(cuda_device):
+    """Error convention of the boundary: invalid problems -> ValueError, missing workspace ->
+    MemoryError, unknown kernel variant -> ValueError; the library never aborts and reports through rydiff_last_error."""
+    import ctypes
+
+    from pulser_diff_amd import _native
+    from pulser_diff_amd.solver import SolverType, evolve
+
+    terms = random_terms(3, 9, 0.004, seed=1)
+    amp, det, u, spec = to_native(terms, cuda_device, SolverType.KRYLOV_SE)
+    psi0 = R.all_ground_state(3).T.contiguous().to(cuda_device)
+    with pytest.raises(ValueError, match="strictly increasing"):
+        evolve(amp, det, u, torch.tensor([0.0, 0.01, 0.01], dtype=torch.float64), psi0, spec, None)
+    with pytest.raises(ValueError, match="Incompatible shape of initial state"):
+        evolve(amp, det, u, torch.tensor([0.0, 0.01], dtype=torch.float64), psi0[:, :4], spec, None)
+    bad = to_native(terms, cuda_device, SolverType.KRYLOV_SE)[3]
+    bad.amp_masks = (0,)
+    with pytest.raises(ValueError, match="term mask"):
+        evolve(amp, det, u, torch.tensor([0.0, 0.01], dtype=torch.float64), psi0, bad, None)
+    with pytest.raises(ValueError):
+        _native.set_kernel_variant(99)
+    # too small a workspace is reported, not overrun
+    L = _native.lib()
+    from pulser_diff_amd.solver import _Call
+    call = _Call(spec, amp.detach(), det.detach(), u, np.array([0.0, 0.01]), 1, None)
+    ws = torch.empty(2048, dtype=torch.uint8, device=cuda_device)
+    states = torch.empty(2, 1, 8, dtype=torch.complex128, device=cuda_device)
+    rc = L.rydiff_forward(ctypes.byref(call.problem), None, ctypes.c_void_p(psi0.data_ptr()), ctypes.c_void_p(states.data_ptr()),
+                          None, ctypes.c_void_p(ws.data_ptr()), ws.numel(), 0, None)
+    assert rc == _native.RYDIFF_EWORKSPACE and "workspace too small" in _native.last_error()
+    with pytest.raises(MemoryError):
+        _native.check(rc)
