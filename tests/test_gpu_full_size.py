@@ -108,9 +108,14 @@ def test_time_reversal_returns_the_initial_state(cuda_device):
     psi0 = (psi0 / psi0.norm(dim=1, keepdim=True)).to(cuda_device)
     spec = ProblemSpec(n, 0.001, T + 1, (mask,), (mask,), solver=SolverType.KRYLOV_SE, store_states=True)
     fwd, _ = evolve(amp, det, u, tsave, psi0, spec, None)
-    # reversed schedule: step k of the return trip uses H(t_{T-k}) with the opposite sign; samples sit at integer ns so
-    # reversing the tables (shifted by one) reproduces the same right-endpoint coefficients in reverse order
-    amp_r = -torch.flip(amp, dims=[2]).roll(1, dims=2)
-    det_r = -torch.flip(det, dims=[2]).roll(1, dims=2)
-    back, _ = evolve(amp_r, det_r, -u, tsave, fwd[-1], spec, None)
+    # return trip: step k' must use -H of forward step T-1-k'.  Forward step k reads sample min(k+1, T-1) (the reference's
+    # interpolation never reads the last sample, hamiltonian.py:532-533); give the return trip one extra sample so that
+    # its own clamp is not hit.
+    idx_fwd = torch.clamp(torch.arange(T) + 1, max=T - 1)
+    src = torch.zeros(T + 2, dtype=torch.long)
+    src[1:T + 1] = idx_fwd.flip(0)
+    amp_r = -amp[:, :, src.to(cuda_device)]
+    det_r = -det[:, :, src.to(cuda_device)]
+    spec_r = ProblemSpec(n, 0.001, T + 2, (mask,), (mask,), solver=SolverType.KRYLOV_SE, store_states=True)
+    back, _ = evolve(amp_r, det_r, -u, tsave, fwd[-1], spec_r, None)
     assert (back[-1] - psi0).abs().max().item() < 1e-10
