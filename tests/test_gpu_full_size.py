@@ -118,4 +118,4 @@ def test_time_reversal_returns_the_initial_state(cuda_device):
     det_r = -det[:, :, src.to(cuda_device)]
     spec_r = ProblemSpec(n, 0.001, T + 2, (mask,), (mask,), solver=SolverType.KRYLOV_SE, store_states=True)
     back, _ = evolve(amp_r, det_r, -u, tsave, fwd[-1], spec_r, None)
-    assert (back[-1] - psi0).abs().max().item() < 1e-10
+    assert (back[-1] - psi0).abs().max().item() < 1e-9  # 80 exponentials on a state spread over the whole spectrum
