@@ -278,12 +278,9 @@ inline size_t carve(Plan& pl, int tape_mode, bool need_backward, int chain_slots
     pl.off_members = take(2 * kMaxGroups * sizeof(uint64_t));
     pl.off_coef = take(size_t(pl.Bc) * E * std::max(pl.NC, 1) * sizeof(double));
     pl.off_udiag = take(pl.dim * sizeof(double));
-    // the four work vectors are read / written at the same element index at the same time: skew their base addresses
-    // so that they do not all map to the same memory channel
-    static const size_t skew = std::getenv("RYDIFF_SKEW") ? size_t(std::atol(std::getenv("RYDIFF_SKEW"))) : 0;
-    pl.off_buf0 = take(pl.state_bytes + skew);
-    pl.off_buf1 = take(pl.state_bytes + 2 * skew);
-    pl.off_pp0 = take(pl.state_bytes + 3 * skew);  // partial vectors of the chained passes
+    pl.off_buf0 = take(pl.state_bytes);
+    pl.off_buf1 = take(pl.state_bytes);
+    pl.off_pp0 = take(pl.state_bytes);  // partial vectors of the chained passes
     pl.off_pp1 = take(pl.state_bytes);
     // split interaction diagonal for the two tile layouts: utt[2][4096] + vr[2][tiles][16]
     pl.off_split = take(2 * (4096 + (pl.dim >> 12 ? (pl.dim >> 12) : 1) * 16) * sizeof(double));

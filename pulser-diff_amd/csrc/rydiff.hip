@@ -862,10 +862,6 @@ struct LayoutDesc {
 
 LayoutDesc chain_layout(int N, int which) {
     LayoutDesc d{};
-    static const bool dbg_all_a = std::getenv("RYDIFF_DEBUG_ALL_A") != nullptr;  // timing experiments only (wrong results)
-    static const bool dbg_all_b = std::getenv("RYDIFF_DEBUG_ALL_B") != nullptr;
-    if (dbg_all_a) which = 0;
-    if (dbg_all_b) which = 1;
     if (which == 0) {  // A
         d.lo = kTileBits;
         d.hs = kTileBits;
@@ -1285,92 +1281,6 @@ int launch_persist(int N, const PersistArgs& pa, int B, hipStream_t stream) {
 
 }  // namespace
 
-
-// ---- timing experiment (not part of the product path): 2R2W streaming pass over caller buffers -------------------
-struct DebugArgs {
-    const double2* a; const double2* b; double2* c; double2* d;
-    const double* tab;
-    int lo, hs, hb, has_p, has_q, write_v;
-    unsigned pad[200];
-};
-
-template <int MODE>
-__global__ __launch_bounds__(1024) void k_debug_copy(DebugArgs g) {
-    extern __shared__ __attribute__((aligned(16))) double2 dsh[];
-    const size_t base = size_t(blockIdx.x) * 4096 + size_t(blockIdx.y) * (size_t(1) << 20);
-    double2 x[4], y[4];
-    double tv[4];
-    unsigned idx[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        unsigned i = r * 1024 + threadIdx.x;
-        if (MODE >= 2) { const unsigned lomask = (1u << g.lo) - 1u; i = (i & lomask) | ((i >> g.lo) << g.hs); }
-        idx[r] = i;
-        x[r] = g.a[base + i];
-    }
-    if (MODE < 3 || g.has_p) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) y[r] = g.b[base + idx[r]];
-    }
-    if (MODE >= 4 && g.has_q) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) tv[r] = g.tab[r * 1024 + threadIdx.x];
-    }
-    if (MODE >= 5) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dsh[r * 1024 + threadIdx.x] = x[r];
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) x[r].x += 1e-30 * dsh[(r * 1024 + threadIdx.x) ^ 1].y;
-    }
-    if (MODE < 3 || g.write_v) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) g.c[base + idx[r]] = x[r];
-    }
-    if (MODE >= 3 && !g.has_q) return;
-    if (MODE >= 5) {
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dsh[r * 1024 + threadIdx.x] = y[r];
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) y[r].x += 1e-30 * dsh[(r * 1024 + threadIdx.x) ^ 2].y;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        if (MODE >= 4) y[r].y += 1e-30 * tv[r];
-        g.d[base + idx[r]] = y[r];
-    }
-}
-
-template <int MODE>
-void debug_launch(DebugArgs g, unsigned nb, size_t lds, hipStream_t stream) {
-    auto kern = k_debug_copy<MODE>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-    hipLaunchKernelGGL(kern, dim3(nb, 1), dim3(1024), lds, stream, g);
-}
-
-extern "C" int rydiff_debug_copy(void* buf, size_t n_elems, int iters, int mode, void* stream_) {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    double2* b0 = static_cast<double2*>(buf);
-    double2 *b1 = b0 + n_elems, *b2 = b1 + n_elems, *b3 = b2 + n_elems;
-    DebugArgs g{};
-    g.tab = reinterpret_cast<const double*>(b3 + n_elems);
-    g.lo = 12; g.hs = 12; g.hb = 0; g.has_p = 1; g.has_q = 1; g.write_v = 1;
-    const unsigned nb = unsigned(n_elems / 4096);
-    for (int it = 0; it < iters; ++it) {
-        if (it & 1) { g.a = b2; g.b = b3; g.c = b0; g.d = b1; } else { g.a = b0; g.b = b1; g.c = b2; g.d = b3; }
-        switch (mode) {
-            case 0: debug_launch<0>(g, nb, 0, stream); break;
-            case 1: debug_launch<1>(g, nb, 65536 + 256, stream); break;
-            case 2: debug_launch<2>(g, nb, 65536 + 256, stream); break;
-            case 3: debug_launch<3>(g, nb, 65536 + 256, stream); break;
-            case 4: debug_launch<4>(g, nb, 65536 + 256, stream); break;
-            default: debug_launch<5>(g, nb, 65536 + 256, stream); break;
-        }
-    }
-    return 0;
-}
 
 // ------------------------------------------------------------------------------------------------
 // C ABI
