@@ -519,6 +519,17 @@ __global__ __launch_bounds__(256) void k_inject(double2* __restrict__ lam, const
     lam[o_] = acc;
 }
 
+// which save points carry a non-zero expectation cotangent (a loss on the final time leaves all others empty):
+// flags[k] = any_{o,b} gexp[o][k][b] != 0
+__global__ void k_cotangent_flags(const double* __restrict__ gexp, int n_obs, int n_tsave, int B, int32_t* __restrict__ flags) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_tsave) return;
+    int any = 0;
+    for (int o = 0; o < n_obs; ++o)
+        for (int b = 0; b < B; ++b) any |= gexp[(size_t(o) * n_tsave + k) * B + b] != 0.0;
+    flags[k] = any;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K5: scatter per-exponential coefficient gradients back onto the sampled tables and tsave.
 // one thread per (exponential, trajectory); atomics because several exponentials touch one sample.
@@ -1487,6 +1498,17 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
 
     HIP_TRY(hipMemsetAsync(ge, 0, size_t(pl.Bc) * E * ge_rec * sizeof(double), stream));
     if (wtot) HIP_TRY(hipMemsetAsync(wtot, 0, pl.dim * sizeof(double), stream));
+    // save points without any cotangent need no injection pass (with only grad_expect given this is decided up front:
+    // one tiny kernel + one copy; the scatter metadata region is free until the end of the sweep)
+    std::vector<int32_t> inject_at(pl.T + 1, 1);
+    if (!gst && have_gexp) {
+        int32_t* dflags = reinterpret_cast<int32_t*>(ws + pl.off_meta2);
+        hipLaunchKernelGGL(k_cotangent_flags, dim3(unsigned(pl.T + 1 + 255) / 256), dim3(256), 0, stream, grad_expect, pl.n_obs,
+                           pl.T + 1, pl.B, dflags);
+        LAUNCH_CHECK();
+        HIP_TRY(hipMemcpyAsync(inject_at.data(), dflags, size_t(pl.T + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
     dim3 grid(unsigned((pl.dim + 255) / 256), pl.B);
     int cl = 0;
     // where the state at tsave[k] lives: one entry per tsave, or (full tape) one entry per factor pass
@@ -1592,7 +1614,7 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
             LAUNCH_CHECK();
             cl ^= 1;
         }
-        if (gst || have_gexp) {
+        if ((gst || have_gexp) && inject_at[k]) {
             hipLaunchKernelGGL(k_inject, grid, dim3(256), 0, stream, lam[cl], gst ? gst + size_t(k) * sv : nullptr,
                                state_at(k), obs, have_gexp ? grad_expect : nullptr, pl.n_obs, pl.T + 1, k, pl.B,
                                uint32_t(pl.dim), 0);
