@@ -359,112 +359,3 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
 #pragma unroll
     for (int r = 0; r < R; ++r) stream_store(a.q_out + boff + xg[r], q[r]);
 }
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Persistent single-workgroup propagator for small registers (N <= 12): the whole trajectory in ONE launch.
-// One workgroup per trajectory keeps its 2^N amplitudes in registers + LDS and loops over every factor of every time
-// step; per-factor scalars come from a device table, coefficients from the expanded records.  Removes ~10^4 launch
-// latencies from a 1000-step run (BASELINE configs 1 and 2), where a 64 KiB state makes every launch latency-bound.
-// ---------------------------------------------------------------------------------------------------------------------
-struct PersistFactor {
-    double gr, gi, br, bi;
-    int stage;
-    int save_index;  // k+1 when this factor ends tsave interval k (state is stored / observed), else 0
-};
-
-struct PersistArgs {
-    const double2* psi0;      // [B][dim]
-    double2* states;          // [n_tsave][B][dim] or nullptr
-    const double* udiag;      // [dim]
-    const double* coef;       // [Bc][E][NC]
-    long coef_bstride;
-    int NC;
-    const PersistFactor* factors;
-    int n_factors;
-    const double* obs;        // [n_obs][dim] or nullptr
-    double* expect;           // [n_obs][n_tsave][B]
-    int n_obs, n_tsave, B;
-    uint32_t dim;
-    int ga, gd;
-    uint32_t amask[kMaxGroups];
-    uint32_t dmask[kMaxGroups];
-    int dcnt[kMaxGroups];
-};
-
-template <int LT, int LGT, bool CPLX>
-__global__ __launch_bounds__(1 << LGT) void k_persist(PersistArgs a) {
-    constexpr int NT = 1 << LGT, R = 1 << (LT - LGT);
-    __shared__ __attribute__((aligned(16))) double2 tile[1 << LT];
-    __shared__ double red[16];
-    const unsigned tid = threadIdx.x;
-    const int b = blockIdx.x;
-    const size_t boff = size_t(b) * a.dim;
-    double2 v[R];
-    double ud[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const unsigned x = unsigned(r) * NT + tid;
-        v[r] = a.psi0[boff + x];
-        ud[r] = a.udiag[x];
-        tile[x] = v[r];
-    }
-    __syncthreads();
-    for (int f = 0; f < a.n_factors; ++f) {
-        const PersistFactor pf = a.factors[f];
-        const double* __restrict__ cf = a.coef + size_t(b) * a.coef_bstride + size_t(pf.stage) * a.NC;
-        double2 q[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const unsigned x = unsigned(r) * NT + tid;
-            double d = ud[r];
-            for (int g = 0; g < a.gd; ++g) d += cf[2 * a.ga + g] * double(a.dcnt[g] - __popc(x & a.dmask[g]));
-            const double dr = pf.gr + pf.br * d, di = pf.gi + pf.bi * d;
-            q[r].x = dr * v[r].x - di * v[r].y;
-            q[r].y = dr * v[r].y + di * v[r].x;
-        }
-        for (int g = 0; g < a.ga; ++g) {
-            double2 ts[R], ds[R];
-            partner_sums<LT, LGT, CPLX>(tile, v, a.amask[g], tid, ts, ds);
-            const double cr = cf[g], ci = cf[a.ga + g];
-            const double k1r = pf.br * cr, k1i = pf.bi * cr, k2r = -pf.bi * ci, k2i = pf.br * ci;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                q[r].x += k1r * ts[r].x - k1i * ts[r].y;
-                q[r].y += k1r * ts[r].y + k1i * ts[r].x;
-                if (CPLX) {
-                    q[r].x += k2r * ds[r].x - k2i * ds[r].y;
-                    q[r].y += k2r * ds[r].y + k2i * ds[r].x;
-                }
-            }
-        }
-        __syncthreads();  // every partner read of the old vector is done
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            v[r] = q[r];
-            tile[unsigned(r) * NT + tid] = q[r];
-        }
-        if (pf.save_index) {
-            if (a.states) {
-                double2* dst = a.states + (size_t(pf.save_index) * a.B + b) * a.dim;
-#pragma unroll
-                for (int r = 0; r < R; ++r) dst[unsigned(r) * NT + tid] = v[r];
-            }
-            for (int o = 0; o < a.n_obs; ++o) {
-                double e = 0.0;
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-                    e += a.obs[size_t(o) * a.dim + unsigned(r) * NT + tid] * (v[r].x * v[r].x + v[r].y * v[r].y);
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) e += __shfl_down(e, off, 64);
-                if ((tid & 63) == 0) red[tid >> 6] = e;
-                __syncthreads();
-                if (tid == 0) {
-                    double s2 = 0.0;
-                    for (int w = 0; w < (NT + 63) / 64; ++w) s2 += red[w];
-                    a.expect[(size_t(o) * a.n_tsave + pf.save_index) * a.B + b] = s2;  // single writer: deterministic
-                }
-            }
-        }
-        __syncthreads();
-    }
-}

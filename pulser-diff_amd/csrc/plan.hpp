@@ -264,7 +264,7 @@ inline bool build_plan(const RydProblem* p, Plan& pl, std::string& err) {
 // needs total_factors+1 states of HBM — e.g. 156 GiB for N=20, T=1000, which an MI355X's 288 GB holds)
 inline size_t carve(Plan& pl, int tape_mode, bool need_backward, int chain_slots, int64_t total_factors = 0) {
     // factor table of the persistent small-N kernel: 40 bytes per factor pass
-    pl.ptable_bytes = pl.N <= 12 ? size_t(total_factors) * 40 + 64 : 0;
+    pl.ptable_bytes = pl.N <= 12 ? size_t(total_factors) * 48 + 64 : 0;  // sizeof(PersistFactor)
     const size_t E = pl.stages.size();
     size_t off = 0;
     auto take = [&](size_t bytes) {

@@ -604,6 +604,8 @@ __global__ void k_scatter_grads(ScatterArgs a) {
 }
 
 #include "chain_kernels.hpp"
+#include "persist_kernels.hpp"
+static_assert(sizeof(PersistFactor) == 48, "plan.hpp sizes the factor table with 48 bytes per entry");
 #include "chain2_kernels.hpp"
 
 // ------------------------------------------------------------------------------------------------
@@ -1267,7 +1269,11 @@ bool persist_enabled(const Runtime& rt) { return g_kernel_variant != 1 && rt.pl.
 template <int LT, bool CPLX>
 int launch_persist_t(const PersistArgs& pa, int B, hipStream_t stream) {
     constexpr int LGT = LT < 10 ? LT : 10;
-    hipLaunchKernelGGL((k_persist<LT, LGT, CPLX>), dim3(B), dim3(1 << LGT), 0, stream, pa);
+    const dim3 block(LGT < 6 ? 64 : (1 << LGT));
+    if (pa.ga <= kPersistGroups && pa.gd <= kPersistGroups)
+        hipLaunchKernelGGL((k_persist<LT, LGT, CPLX, true>), dim3(B), block, 0, stream, pa);
+    else
+        hipLaunchKernelGGL((k_persist<LT, LGT, CPLX, false>), dim3(B), block, 0, stream, pa);
     LAUNCH_CHECK();
     return RYDIFF_OK;
 }
@@ -1287,6 +1293,44 @@ int launch_persist(int N, const PersistArgs& pa, int B, hipStream_t stream) {
         case 10: return launch_persist_t<10, CPLX>(pa, B, stream);
         case 11: return launch_persist_t<11, CPLX>(pa, B, stream);
         default: return launch_persist_t<12, CPLX>(pa, B, stream);
+    }
+}
+
+template <int LT, bool CPLX>
+int launch_persist_bwd_t(const PersistBwdArgs& pa, int B, hipStream_t stream) {
+    constexpr int LGT = LT < 10 ? LT : 9;  // 1024+ amplitudes: 512 threads, so the accumulators stay in registers
+    hipLaunchKernelGGL((k_persist_bwd<LT, LGT, CPLX>), dim3(B), dim3(LGT < 6 ? 64 : (1 << LGT)), 0, stream, pa);
+    LAUNCH_CHECK();
+    return RYDIFF_OK;
+}
+
+template <bool CPLX>
+int launch_persist_bwd(int N, const PersistBwdArgs& pa, int B, hipStream_t stream) {
+    switch (N) {
+        case 1: return launch_persist_bwd_t<1, CPLX>(pa, B, stream);
+        case 2: return launch_persist_bwd_t<2, CPLX>(pa, B, stream);
+        case 3: return launch_persist_bwd_t<3, CPLX>(pa, B, stream);
+        case 4: return launch_persist_bwd_t<4, CPLX>(pa, B, stream);
+        case 5: return launch_persist_bwd_t<5, CPLX>(pa, B, stream);
+        case 6: return launch_persist_bwd_t<6, CPLX>(pa, B, stream);
+        case 7: return launch_persist_bwd_t<7, CPLX>(pa, B, stream);
+        case 8: return launch_persist_bwd_t<8, CPLX>(pa, B, stream);
+        case 9: return launch_persist_bwd_t<9, CPLX>(pa, B, stream);
+        case 10: return launch_persist_bwd_t<10, CPLX>(pa, B, stream);
+        default: return launch_persist_bwd_t<11, CPLX>(pa, B, stream);
+    }
+}
+
+// every factor of the run, in order, with the save point its output belongs to (0 = none)
+void build_persist_table(const Runtime& rt, std::vector<PersistFactor>& table) {
+    std::vector<ChainItem> chain;
+    table.clear();
+    for (int k = 0; k < rt.pl.T; ++k) {
+        build_step_chain(rt, k, chain);
+        const int first = int(table.size());
+        for (size_t i = 0; i < chain.size(); ++i)
+            table.push_back({chain[i].s.gr, chain[i].s.gi, chain[i].s.br, chain[i].s.bi, chain[i].stage,
+                             i + 1 == chain.size() ? k + 1 : 0, first, 0});
     }
 }
 
@@ -1376,12 +1420,7 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
     if (persist_enabled(rt)) {
         // whole trajectory in one launch; the factor table goes to the (otherwise unused) first ping-pong buffer region
         std::vector<PersistFactor> table;
-        for (int k = 0; k < pl.T; ++k) {
-            build_step_chain(rt, k, chain);
-            for (size_t i = 0; i < chain.size(); ++i)
-                table.push_back({chain[i].s.gr, chain[i].s.gi, chain[i].s.br, chain[i].s.bi, chain[i].stage,
-                                 i + 1 == chain.size() ? k + 1 : 0});
-        }
+        build_persist_table(rt, table);
         const size_t tbytes = table.size() * sizeof(PersistFactor);
         if (tbytes > pl.ptable_bytes) return fail(RYDIFF_EWORKSPACE, "internal: factor table does not fit");
         PersistFactor* dtab = reinterpret_cast<PersistFactor*>(ws + pl.off_ptable);
@@ -1498,17 +1537,6 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
 
     HIP_TRY(hipMemsetAsync(ge, 0, size_t(pl.Bc) * E * ge_rec * sizeof(double), stream));
     if (wtot) HIP_TRY(hipMemsetAsync(wtot, 0, pl.dim * sizeof(double), stream));
-    // save points without any cotangent need no injection pass (with only grad_expect given this is decided up front:
-    // one tiny kernel + one copy; the scatter metadata region is free until the end of the sweep)
-    std::vector<int32_t> inject_at(pl.T + 1, 1);
-    if (!gst && have_gexp) {
-        int32_t* dflags = reinterpret_cast<int32_t*>(ws + pl.off_meta2);
-        hipLaunchKernelGGL(k_cotangent_flags, dim3(unsigned(pl.T + 1 + 255) / 256), dim3(256), 0, stream, grad_expect, pl.n_obs,
-                           pl.T + 1, pl.B, dflags);
-        LAUNCH_CHECK();
-        HIP_TRY(hipMemcpyAsync(inject_at.data(), dflags, size_t(pl.T + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-    }
     dim3 grid(unsigned((pl.dim + 255) / 256), pl.B);
     int cl = 0;
     // where the state at tsave[k] lives: one entry per tsave, or (full tape) one entry per factor pass
@@ -1520,15 +1548,82 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
         fprefix[k + 1] = fprefix[k] + f;
     }
     auto state_at = [&](int k) -> const double2* { return tape + size_t(full_tape ? fprefix[k] : k) * sv; };
-    // cotangent at the final time
-    hipLaunchKernelGGL(k_inject, grid, dim3(256), 0, stream, lam[cl], gst ? gst + size_t(pl.T) * sv : nullptr,
-                       state_at(pl.T), obs, have_gexp ? grad_expect : nullptr, pl.n_obs, pl.T + 1, pl.T, pl.B,
-                       uint32_t(pl.dim), 1);
-    LAUNCH_CHECK();
+
+    std::vector<int32_t> inject_at(pl.T + 1, 1);
+    // small registers: the whole reverse sweep in one launch (k_persist_bwd)
+    // (4096 amplitudes would need 8 per thread plus the accumulators: past the register file, so N = 12 keeps the launch-per-factor sweep)
+    const bool persisted = persist_enabled(rt) && pl.N <= kPersistBwdMaxQubits && !full_tape && pl.ga.n <= kPersistGroups &&
+                           pl.gd.n <= kPersistGroups &&
+                           rt.max_step_factors <= kStageChunk;
+    if (persisted) {
+        std::vector<PersistFactor> table;
+        build_persist_table(rt, table);
+        const size_t tbytes = table.size() * sizeof(PersistFactor);
+        if (tbytes > pl.ptable_bytes) return fail(RYDIFF_EWORKSPACE, "internal: factor table does not fit");
+        if (rt.max_step_factors - 1 > pl.chain_slots) return fail(RYDIFF_EWORKSPACE, "internal: chain buffers too small");
+        PersistFactor* dtab = reinterpret_cast<PersistFactor*>(ws + pl.off_ptable);
+        HIP_TRY(hipMemcpyAsync(dtab, table.data(), tbytes, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        int32_t* dflags = nullptr;
+        if (have_gexp) {  // stays on the device: the sweep skips save points without an expectation cotangent
+            dflags = reinterpret_cast<int32_t*>(ws + pl.off_meta2);
+            hipLaunchKernelGGL(k_cotangent_flags, dim3(unsigned(pl.T + 1 + 255) / 256), dim3(256), 0, stream, grad_expect,
+                               pl.n_obs, pl.T + 1, pl.B, dflags);
+            LAUNCH_CHECK();
+        }
+        PersistBwdArgs pa{};
+        pa.gflags = dflags;
+        pa.tape = tape;
+        pa.chainbuf = chainbuf;
+        pa.gstate = gst;
+        pa.gexp = have_gexp ? grad_expect : nullptr;
+        pa.obs = obs;
+        pa.udiag = udiag;
+        pa.coef = coef;
+        pa.coef_bstride = coef_bstride;
+        pa.NC = pl.NC;
+        pa.factors = dtab;
+        pa.n_factors = int(table.size());
+        pa.ge = ge;
+        pa.ge_bstride = ge_bstride;
+        pa.ge_sstride = ge_rec;
+        pa.wtot = wtot;
+        pa.mu_out = lam[cl];
+        pa.want_tau = g_tsave ? 1 : 0;
+        pa.n_obs = have_gexp ? pl.n_obs : 0;
+        pa.n_tsave = pl.T + 1;
+        pa.B = pl.B;
+        pa.dim = uint32_t(pl.dim);
+        pa.ga = pl.ga.n;
+        pa.gd = pl.gd.n;
+        for (int g = 0; g < pl.ga.n; ++g) pa.amask[g] = pl.ga.amp_index_mask[g];
+        for (int g = 0; g < pl.gd.n; ++g) {
+            pa.dmask[g] = pl.gd.amp_index_mask[g];
+            pa.dcnt[g] = pl.gd.count[g];
+        }
+        rc = (rt.flags & 1) ? launch_persist_bwd<true>(pl.N, pa, pl.B, stream) : launch_persist_bwd<false>(pl.N, pa, pl.B, stream);
+        if (rc) return rc;
+    } else {
+        // save points without any cotangent need no injection pass (with only grad_expect given this is decided up front:
+        // one tiny kernel + one copy; the scatter metadata region is free until the end of the sweep)
+        if (!gst && have_gexp) {
+            int32_t* dflags = reinterpret_cast<int32_t*>(ws + pl.off_meta2);
+            hipLaunchKernelGGL(k_cotangent_flags, dim3(unsigned(pl.T + 1 + 255) / 256), dim3(256), 0, stream, grad_expect, pl.n_obs,
+                               pl.T + 1, pl.B, dflags);
+            LAUNCH_CHECK();
+            HIP_TRY(hipMemcpyAsync(inject_at.data(), dflags, size_t(pl.T + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+        }
+        // cotangent at the final time
+        hipLaunchKernelGGL(k_inject, grid, dim3(256), 0, stream, lam[cl], gst ? gst + size_t(pl.T) * sv : nullptr,
+                           state_at(pl.T), obs, have_gexp ? grad_expect : nullptr, pl.n_obs, pl.T + 1, pl.T, pl.B,
+                           uint32_t(pl.dim), 1);
+        LAUNCH_CHECK();
+    }
 
     std::vector<ChainItem> chain;
     std::vector<const double2*> xs;
-    for (int k = pl.T - 1; k >= 0; --k) {
+    for (int k = persisted ? -1 : pl.T - 1; k >= 0; --k) {
         build_step_chain(rt, k, chain);
         const int M = int(chain.size());
         if (M - 1 > pl.chain_slots) return fail(RYDIFF_EWORKSPACE, "internal: chain buffers too small");

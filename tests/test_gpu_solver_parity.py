@@ -176,6 +176,46 @@ def test_twelve_qubit_chain_against_matrix_free_oracle(cuda_device):
     assert rel_err(states[-1].cpu().numpy().T, ref[-1]) < STATE_RTOL
 
 
+# ---- persistent single-launch adjoint (N <= 11) ---------------------------------------------------------------------
+@pytest.mark.parametrize("n_qubits,solver_name,batch_tables", [(1, "KRYLOV_SE", 1), (3, "DP5_SE", 1), (6, "KRYLOV_SE", 2),
+                                                              (9, "DP5_SE", 1), (10, "KRYLOV_SE", 1), (11, "KRYLOV_SE", 2)])
+def test_persistent_adjoint_matches_per_factor_launches(cuda_device, n_qubits, solver_name, batch_tables):
+    """A/B on the GPU: the one-launch reverse sweep (k_persist_bwd: 1, 2 and 4 amplitudes per thread, factor inputs
+    parked in LDS or in the global scratch slots, Magnus stages of the continuous solver) against the per-factor
+    launches, which are pinned to the oracle's autograd above.  All five gradients, cotangents on states AND on
+    expectation values at every save point, shared and per-trajectory tables."""
+    from pulser_diff_amd import _native
+    from pulser_diff_amd.solver import SolverType, evolve
+
+    terms = random_terms(n_qubits, 33, 0.004, seed=300 + n_qubits, local=n_qubits > 1)
+    tsave0 = torch.cat([torch.zeros(1, dtype=torch.float64), torch.linspace(0.011, 0.12, 6, dtype=torch.float64)])
+    gen = torch.Generator().manual_seed(n_qubits)
+    psi = torch.randn(2, 2**n_qubits, generator=gen, dtype=torch.complex128)
+    psi = (psi / psi.norm(dim=1, keepdim=True)).to(cuda_device)
+    obs = torch.stack([R.total_magnetization_diag(n_qubits), torch.rand(2**n_qubits, generator=gen, dtype=torch.float64)]).to(cuda_device)
+    probe = torch.randn(2**n_qubits, generator=gen, dtype=torch.complex128).to(cuda_device)
+    out = {}
+    for variant in (1, 0):
+        _native.set_kernel_variant(variant)
+        try:
+            amp, det, u, spec = to_native(terms, cuda_device, getattr(SolverType, solver_name), batch_tables=batch_tables)
+            if batch_tables == 2:
+                amp = amp * torch.tensor([1.0, 0.8], device=cuda_device)[:, None, None]
+            leaves = [amp.detach().clone().requires_grad_(True), det.detach().clone().requires_grad_(True),
+                      u.detach().clone().requires_grad_(True), tsave0.clone().requires_grad_(True), psi.clone().requires_grad_(True)]
+            states, expect = evolve(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], spec, obs)
+            w = torch.linspace(0.5, 1.5, expect.shape[1], dtype=torch.float64, device=cuda_device)
+            loss = (expect[0] * w[:, None]).sum() - 0.3 * expect[1, 3].sum() + ((states[2] + states[-1]) @ probe.conj()).real.sum()
+            loss.backward()
+            out[variant] = [expect.detach().cpu()] + [(t.grad if t.grad is not None else torch.zeros_like(t)).detach().cpu()
+                                                     for t in leaves]  # a single qubit has no pair interactions
+        finally:
+            _native.set_kernel_variant(0)
+    for name, ref, got in zip(("expect", "amp", "det", "u", "tsave", "psi0"), out[1], out[0]):
+        if ref.numel():
+            assert rel_err(got.numpy(), ref.numpy()) < 1e-10, name
+
+
 # ---- LDS-tiled chained kernels (N >= 13) ---------------------------------------------------------------------------
 def _run_variant(variant, terms, tsave, psi_bd, device, obs, grads=True, batch_tables=1):
     from pulser_diff_amd import _native
