@@ -7,22 +7,27 @@ What changes for a user switching over:
   * ``run(..., observables=[DiagonalObservable(...)], store_states=False)`` evaluates diagonal observables natively
     and keeps the trajectory inside the solver workspace — the only way to run a 20-qubit sequence, where a dense
     observable (2^40 entries) or an autograd tape through every sub-step cannot exist;
-  * noise (``SimConfig(noise=...)``), the digital / XY bases and SLM masks raise ``NotImplementedError``.
+  * stochastic noise (``SimConfig(noise=("doppler", "amplitude", "SPAM"))``) runs all realisations as ONE batch of
+    trajectories and returns ``NoisyResults``; noise that needs collapse operators, the digital / XY bases and SLM masks
+    raise ``NotImplementedError``.
 """
 from __future__ import annotations
 
 from bisect import bisect_left
+from collections import Counter
 from dataclasses import replace
 from typing import Any, Optional, Union
 
+import numpy as np
 import torch
 from torch import Tensor
 
 from . import pulses
 from .hamiltonian import Hamiltonian
+from .result import SampledResult
 from .simconfig import SimConfig
-from .simresults import CoherentResults, SimulationResults
-from .solver import SolverType, sesolve
+from .simresults import CoherentResults, NoisyResults, SimulationResults
+from .solver import ProblemSpec, SolverType, evolve, sesolve, tolerance_from_options
 from .utils import DiagonalObservable
 
 
@@ -76,6 +81,7 @@ class TorchEmulator:
         if int(self._tot_duration * sampling_rate) < 4:
             raise ValueError("`sampling_rate` is too small, less than 4 data points.")
         self._compute_device = torch.device(compute_device)
+        self._noisy_state_budget = 8 * 2**30  # bytes of saved states per batch of noise realisations
         noise_model = config.to_noise_model() if config else SimConfig().to_noise_model()
         self._config = config if config else SimConfig()
         self._hamiltonian = Hamiltonian(self.samples_obj, self._register.qubits, device, sampling_rate, noise_model,
@@ -126,10 +132,28 @@ class TorchEmulator:
         self._config = cfg
 
     def add_config(self, config: SimConfig) -> None:
-        """backend.py:200-238 (only noiseless configurations can be merged on this backend)."""
+        """backend.py:200-238: merge another configuration; noise types that are new bring their parameters along,
+        noise types present in both keep the former parameters."""
         if not isinstance(config, SimConfig):
             raise ValueError(f"Object {config} is not a valid `SimConfig`")
-        self.set_config(replace(self._config, noise=tuple(set(self._config.noise) | set(config.noise))))
+        not_supported = set(config.noise) - config.supported_noises[self._hamiltonian._interaction]
+        if not_supported:
+            raise NotImplementedError(
+                f"Interaction mode '{self._hamiltonian._interaction}' does not"
+                " support simulation of noise types: "
+                f"{', '.join(not_supported)}."
+            )
+        params_of = {"SPAM": ("eta", "epsilon", "epsilon_prime"), "doppler": ("temperature",),
+                     "amplitude": ("laser_waist", "amp_sigma"), "relaxation": ("relaxation_rate",),
+                     "dephasing": ("dephasing_rate", "hyperfine_dephasing_rate"), "depolarizing": ("depolarizing_rate",),
+                     "eff_noise": ("eff_noise_rates", "eff_noise_opers")}
+        old = self._config
+        added = [n for n in config.noise if n not in old.noise]
+        changes: dict = {"noise": tuple(old.noise) + tuple(added), "temperature": old.temperature * 1e6}  # stored in K
+        for n in added:
+            for name in params_of.get(n, ()):
+                changes[name] = getattr(config, name) * 1e6 if name == "temperature" else getattr(config, name)
+        self.set_config(replace(old, **changes))
 
     def show_config(self, solver_options: bool = False) -> None:
         print(self.config.__str__(solver_options))
@@ -243,8 +267,6 @@ class TorchEmulator:
                     v.requires_grad_(True)  # constant register: make r_ij a leaf and reconnect U_ij to it
                 self.dist_dict[k] = v
             self._hamiltonian._rebuild_u_pairs()
-        if self.config.noise:
-            raise NotImplementedError("Noisy simulations are not implemented in the MI355X-native backend.")
         if solver == SolverType.DP5_ME:
             raise NotImplementedError("The master-equation solver DP5_ME is not part of the native hot path.")
         if solver not in (SolverType.DP5_SE, SolverType.KRYLOV_SE):
@@ -270,12 +292,89 @@ class TorchEmulator:
         psi0 = self.initial_state
         if psi0.ndim == 1:
             psi0 = psi0.unsqueeze(1)
-        result = sesolve(ham, psi0.to(dev), self._eval_times_array, solver=solver, options=options, obs_diag=obs_diag,
-                         store_states=store_states)
-        states_tbd = result.states.permute(0, 2, 1) if result.states.numel() else result.states
-        return CoherentResults(states_tbd, ham._size, ham.basis_name, self._eval_times_array, self._meas_basis, None,
-                               atom_order=tuple(ham._qdict), native_expect=result.expect if obs_diag is not None else None,
-                               native_observables=obs_objs, stats=result.stats)
+
+        # measurement errors of the SPAM model (backend.py:462-480)
+        noise = set(self.config.noise)
+        meas_errors = None
+        if "SPAM" in noise:
+            meas_errors = {k: self.config.spam_dict[k] for k in ("epsilon", "epsilon_prime")}
+            ground = torch.zeros_like(self.initial_state)
+            ground[-1] = 1.0
+            if self.config.eta > 0 and not torch.equal(self.initial_state, ground):
+                raise NotImplementedError("Can't combine state preparation errors with an initial "
+                                          "state different from the ground.")
+
+        def run_coherent() -> CoherentResults:
+            result = sesolve(ham, psi0.to(dev), self._eval_times_array, solver=solver, options=options, obs_diag=obs_diag,
+                             store_states=store_states)
+            states_tbd = result.states.permute(0, 2, 1) if result.states.numel() else result.states
+            return CoherentResults(states_tbd, ham._size, ham.basis_name, self._eval_times_array, self._meas_basis,
+                                   meas_errors, atom_order=tuple(ham._qdict),
+                                   native_expect=result.expect if obs_diag is not None else None,
+                                   native_observables=obs_objs, stats=result.stats)
+
+        # does the noise ask for averaging over several runs?  (backend.py:531-569)
+        no_resampling = noise <= {"dephasing", "relaxation", "SPAM", "depolarizing", "eff_noise", "amplitude"} and (
+            "amplitude" not in noise or self.config.amp_sigma == 0.0)
+        bad_atom_configs = None
+        if no_resampling:
+            if "SPAM" not in noise or self.config.eta == 0:
+                return run_coherent()
+            # only the state preparation is random: one run per distinct configuration of badly prepared atoms
+            n_atoms = len(ham._qid_index)
+            drawn = Counter("".join(str(int(b)) for b in (torch.rand(size=(n_atoms,)) < self.config.eta).tolist())
+                            for _ in range(self.config.runs)).most_common()
+            bad_atom_configs = [tuple(c == "1" for c in cfg) for cfg, _ in drawn]
+            reps = [r for _, r in drawn]
+        else:
+            reps = [1] * self.config.runs
+        return self._run_noisy(psi0, solver, options, reps, bad_atom_configs, meas_errors)
+
+    def _run_noisy(self, psi0: Tensor, solver: SolverType, options: dict, reps: list, bad_atom_configs,
+                   meas_errors) -> NoisyResults:
+        """backend.py:571-611 with the stochastic runs as the BATCH axis of the native solver: every run is one more
+        trajectory with its own coefficient tables, all advanced by the same launches; the per-run measurements
+        (``samples_per_run`` x repetitions, then detection errors) are drawn on the GPU from |psi(t)|^2."""
+        ham, dev = self._hamiltonian, self._compute_device
+        if psi0.shape[1] != 1:
+            raise NotImplementedError("Noisy runs start from a single initial state.")
+        loop_runs = len(reps)
+        amp, det, amp_masks, det_masks = ham.noisy_batch_tables(loop_runs, bad_atom_configs)
+        n, n_t = ham._size, int(self._eval_times_array.shape[0])
+        dim = 2**n
+        spec = ProblemSpec(n, ham.dt, ham.n_samples, amp_masks, det_masks, solver=solver,
+                           tol=tolerance_from_options(options), store_states=True)
+        # bound the saved states of one batch (n_t x runs x 2^N amplitudes)
+        chunk = max(1, min(loop_runs, int(self._noisy_state_budget // max(n_t * dim * 16, 1))))
+        eps = meas_errors["epsilon"] if meas_errors else 0.0
+        eps_p = meas_errors["epsilon_prime"] if meas_errors else 0.0
+        bit_weights = (1 << torch.arange(n, device=dev, dtype=torch.int64))
+        total_count = [Counter() for _ in range(n_t)]
+        tsave = self._eval_times_array.detach()
+        for r0 in range(0, loop_runs, chunk):
+            r1 = min(loop_runs, r0 + chunk)
+            with torch.no_grad():
+                states, _ = evolve(amp[r0:r1], det[r0:r1], ham.u_pairs.detach(), tsave,
+                                   psi0.to(dev).T.contiguous().repeat(r1 - r0, 1), spec, None)
+                probs = states.real**2 + states.imag**2  # (n_t, runs, dim), basis order r = 0, g = 1
+                del states
+                for b in range(r1 - r0):
+                    n_shots = self.config.samples_per_run * reps[r0 + b]
+                    idx = torch.multinomial(probs[:, b, :], n_shots, replacement=True)  # (n_t, shots)
+                    # measured bitstring: '1' = Rydberg = index bit 0 (result.py:70-120), i.e. the complement of the index
+                    shots = (dim - 1) - idx
+                    if eps > 0 or eps_p > 0:
+                        bits = (shots.unsqueeze(-1) >> torch.arange(n, device=dev)) & 1
+                        flip = torch.rand(bits.shape, device=dev) < torch.where(bits == 1, eps_p, eps)
+                        shots = ((bits ^ flip.to(bits.dtype)) * bit_weights).sum(-1)
+                    shots = shots.cpu().numpy()
+                    for t in range(n_t):
+                        vals, cnt = np.unique(shots[t], return_counts=True)
+                        total_count[t].update({np.binary_repr(int(v), n): int(c) for v, c in zip(vals, cnt)})
+                del probs
+        n_measures = self.config.runs * self.config.samples_per_run
+        results = [SampledResult(tuple(ham._qdict), self._meas_basis, total_count[t]) for t in range(n_t)]
+        return NoisyResults(results, ham._size, ham.basis_name, self._eval_times_array, n_measures)
 
     @classmethod
     def from_sequence(cls, sequence, sampling_rate: float = 1.0, config: Optional[SimConfig] = None,

@@ -12,11 +12,15 @@ constructor arguments produce the *structure* only:
 
 and the native library applies H(t) to the state without ever materialising it.  ``_hamiltonian(t)`` (used by
 ``TorchEmulator.get_hamiltonian``, ``backend.py:401-427``) still returns an explicit matrix for small registers.
-Only the ground-rydberg ("ising") basis without noise is on the hot path; other modes raise NotImplementedError.
+Only the ground-rydberg ("ising") basis is on the hot path.  Stochastic noise (doppler, amplitude, SPAM;
+``hamiltonian.py:170-219,270-286``) is a perturbation of the sampled coefficient arrays, i.e. more trajectories of the same
+Schroedinger problem: ``noisy_batch_tables`` draws all realisations at once and returns per-run tables for ONE batched
+call of the native solver.  Noise types that need collapse operators (Lindblad) raise NotImplementedError.
 """
 from __future__ import annotations
 
 import itertools
+import math
 from math import floor
 from typing import Callable, Union
 
@@ -29,6 +33,16 @@ from .utils import basis_state, kron
 
 CD = torch.complex128
 RD = torch.float64
+STOCHASTIC_NOISES = {"doppler", "amplitude", "SPAM"}  # realised as extra trajectories; the rest needs collapse operators
+# pulser_simulation.simconfig.doppler_sigma (not vendored in the reference; published constants of pulser-simulation):
+# thermal Doppler shift of the effective Rydberg transition wave vector for 87Rb
+_KB, _MASS, _KEFF = 1.38e-23, 1.45e-25, 8.7  # J/K, kg, 1/um
+
+
+def doppler_sigma(temperature: float) -> float:
+    """Standard deviation (rad/us) of the Doppler detuning at ``temperature`` (K)."""
+    return _KEFF * (_KB * temperature / _MASS) ** 0.5
+
 MAX_EXPLICIT_QUBITS = 14  # explicit operators (build_operator / get_hamiltonian) are for small registers only
 
 
@@ -78,16 +92,19 @@ class Hamiltonian:
                 f"Interaction mode '{self._interaction}' does not support "
                 f"simulation of noise types: {', '.join(not_supported)}."
             )
-        if cfg.noise_types:
+        lindblad = set(cfg.noise_types) - STOCHASTIC_NOISES
+        if lindblad:
             raise NotImplementedError(
-                "The MI355X-native backend accelerates the noiseless Schroedinger path; noise types "
-                f"{cfg.noise_types} (collapse operators / stochastic runs) are not implemented."
+                "The MI355X-native backend accelerates the Schroedinger path; noise types "
+                f"{sorted(lindblad)} need collapse operators (master equation) and are not implemented."
             )
         if not hasattr(self, "basis_name"):
             self._build_basis_and_op_matrices()
         self._config = cfg
-        self._bad_atoms = {qid: False for qid in self._qid_index}
-        self._doppler_detune = {qid: 0.0 for qid in self._qid_index}
+        if not ("SPAM" in cfg.noise_types and cfg.state_prep_error > 0):
+            self._bad_atoms = {qid: False for qid in self._qid_index}
+        if "doppler" not in cfg.noise_types:
+            self._doppler_detune = {qid: 0.0 for qid in self._qid_index}
         self._construct_hamiltonian()
 
     def _build_basis_and_op_matrices(self) -> None:
@@ -103,9 +120,86 @@ class Hamiltonian:
         for proj in projectors:
             self.op_matrix["sigma_" + proj] = (self.basis[proj[0]] * self.basis[proj[1]].mH).to_sparse()
 
+    def _update_noise(self) -> None:
+        """hamiltonian.py:270-286: new random noise parameters (badly prepared atoms, Doppler detunings)."""
+        cfg = self._config
+        n = len(self._qid_index)
+        if "SPAM" in cfg.noise_types and cfg.state_prep_error > 0:
+            dist = torch.rand(size=(n,)) < cfg.state_prep_error
+            self._bad_atoms = dict(zip(self._qid_index, dist.tolist()))
+        if "doppler" in cfg.noise_types:
+            detune = torch.normal(0.0, doppler_sigma(cfg.temperature * 1e-6), size=(n,))
+            self._doppler_detune = dict(zip(self._qid_index, detune.tolist()))
+
+    def _local_noises(self) -> bool:
+        """Whether the samples have to be expanded per qubit (hamiltonian.py:172-177)."""
+        cfg = self._config
+        if set(cfg.noise_types).issubset({"dephasing", "relaxation", "SPAM", "depolarizing", "eff_noise"}):
+            return "SPAM" in cfg.noise_types and cfg.state_prep_error > 0
+        return True
+
     def _extract_samples(self) -> None:
-        """hamiltonian.py:170-219 without the noise branches."""
-        self.samples = self.samples_obj.to_nested_dict(all_local=False, samples_type="tensor")
+        """hamiltonian.py:170-219: the samples dictionary, with the current noise realisation applied per qubit."""
+        cfg = self._config
+        local_noises = self._local_noises()
+        samples = self.samples_obj.to_nested_dict(all_local=local_noises, samples_type="tensor")
+        if local_noises:
+            for basis in samples["Local"]:
+                for qid in samples["Local"][basis]:
+                    for qty in ("amp", "det", "phase"):
+                        samples["Local"][basis][qid][qty] = samples["Local"][basis][qid][qty].detach().clone()
+            for ch, ch_samples in self.samples_obj.channel_samples.items():
+                info = self.samples_obj._ch_objs[ch]
+                samples_dict = samples["Local"][info.basis]
+                for slot in ch_samples.slots:
+                    # one amplitude fluctuation per pulse, shared by its targets (drawn for every pulse, as the reference does)
+                    noise_amp_base = max(0.0, float(torch.normal(torch.tensor([1.0]), cfg.amp_sigma)))
+                    for qid in slot.targets:
+                        if "doppler" in cfg.noise_types:
+                            samples_dict[qid]["det"][slot.ti:slot.tf] += self._doppler_detune[qid]
+                        if "amplitude" in cfg.noise_types and info.addressing == "Global":  # Gaussian beam profile
+                            amp_fraction = 1.0
+                            if cfg.laser_waist is not None:
+                                r = float(torch.linalg.norm(self._qdict[qid]))
+                                amp_fraction = math.exp(-((r / float(cfg.laser_waist)) ** 2))
+                            samples_dict[qid]["amp"][slot.ti:slot.tf] *= noise_amp_base * amp_fraction
+            for basis in samples["Local"]:  # badly prepared atoms do not see the pulses
+                for qid in samples["Local"][basis]:
+                    if self._bad_atoms[qid]:
+                        for qty in ("amp", "det", "phase"):
+                            samples["Local"][basis][qid][qty] = torch.zeros_like(samples["Local"][basis][qid][qty])
+        self.samples = samples
+
+    def noisy_batch_tables(self, n_runs: int, bad_atoms: Union[list, None] = None):
+        """Coefficient tables of ``n_runs`` noise realisations as ONE batch: (amp_tables [R, K_a, n], det_tables
+        [R, K_d, n], amp_masks, det_masks), one single-qubit term per addressed atom.  ``bad_atoms`` (list of per-atom
+        bool tuples) fixes the state-preparation errors of each run instead of redrawing all noise
+        (``backend.py:575-587``: ``update=False``)."""
+        n, ns = self._size, int(self._sampling_rate * self._duration)
+        amp = torch.zeros(n_runs, n, ns, dtype=CD)
+        det = torch.zeros(n_runs, n, ns, dtype=RD)
+        keep = (self._bad_atoms, self._doppler_detune, getattr(self, "samples", None))
+        for r in range(n_runs):
+            if bad_atoms is not None:
+                self._bad_atoms = dict(zip(self._qid_index, (bool(b) for b in bad_atoms[r])))
+            else:
+                self._update_noise()
+            self._extract_samples()
+            if self.samples["Global"]:
+                raise RuntimeError("noise realisations need per-qubit samples")
+            for basis, per_q in self.samples["Local"].items():
+                if basis != "ground-rydberg":
+                    raise NotImplementedError("Only the ground-rydberg basis is supported.")
+                for qid, sq in per_q.items():
+                    j = self._qid_index[qid]
+                    amp[r, j] = self._adapt_to_sampling_rate(0.5 * sq["amp"] * torch.exp(-1j * sq["phase"].to(CD)))
+                    det[r, j] = self._adapt_to_sampling_rate(-0.5 * sq["det"])
+        self._bad_atoms, self._doppler_detune, self.samples = keep
+        ka = [j for j in range(n) if bool(torch.any(amp[:, j] != 0))]
+        kd = [j for j in range(n) if bool(torch.any(det[:, j] != 0))]
+        dev = self._compute_device
+        return (amp[:, ka].contiguous().to(dev), det[:, kd].contiguous().to(dev), tuple(1 << j for j in ka),
+                tuple(1 << j for j in kd))
 
     def build_operator(self, operations: Union[list, tuple]) -> Tensor:
         """hamiltonian.py:221-268 (explicit operator; small registers only)."""
@@ -138,6 +232,8 @@ class Hamiltonian:
     # ------------------------------------------------------------------------------------------------------
     def _construct_hamiltonian(self, update: bool = True) -> None:
         """hamiltonian.py:320-497 for the ising / ground-rydberg mode: structure instead of matrices."""
+        if update:
+            self._update_noise()
         self._extract_samples()
         n = self._size
         # pair interactions, hamiltonian.py:333-344 (U = C6/dist^6 after the reference's 0.5 * ... and 2 * int_mat)

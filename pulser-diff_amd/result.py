@@ -69,3 +69,39 @@ class TorchResult:
     def get_state(self, reduce_to_basis=None, ignore_global_phase: bool = True, tol: float = 1e-6,
                   normalize: bool = True) -> Tensor:
         raise NotImplementedError("Not rewritten with torch")  # result.py:150
+
+
+@dataclass
+class SampledResult:
+    """Bitstring counts of one evaluation time of a noisy run: the fields and helpers of ``pulser.result.SampledResult``
+    the reference uses (``backend.py:597-604``, ``simresults.py:225-311``)."""
+
+    atom_order: tuple
+    meas_basis: str
+    bitstring_counts: dict
+
+    def __post_init__(self) -> None:
+        self.n_samples = int(sum(self.bitstring_counts.values()))
+
+    @property
+    def _size(self) -> int:
+        return len(self.atom_order)
+
+    @property
+    def sampling_dist(self) -> dict:
+        return {bitstr: count / self.n_samples for bitstr, count in self.bitstring_counts.items()}
+
+    @property
+    def sampling_errors(self) -> dict:
+        """Standard error of the mean of each bitstring's sampling rate."""
+        return {bitstr: float(np.sqrt(p * (1 - p) / self.n_samples)) for bitstr, p in self.sampling_dist.items()}
+
+    def _weights(self) -> np.ndarray:
+        weights = np.zeros(2**self._size)
+        for bitstr, count in self.bitstring_counts.items():
+            weights[int(bitstr, 2)] = count / self.n_samples
+        return weights / weights.sum()
+
+    def get_samples(self, n_samples: int) -> Counter:
+        counts = np.random.multinomial(n_samples, self._weights())
+        return Counter({np.binary_repr(i, self._size): int(c) for i, c in enumerate(counts) if c > 0})

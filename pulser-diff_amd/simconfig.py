@@ -1,10 +1,11 @@
 """``SimConfig`` with the reference's field names (``pulser_diff/simconfig.py:16`` on top of
 ``pulser_simulation.SimConfig``), standalone: neither pulser_simulation nor qutip is needed.
 
-The hot path this backend accelerates is the noiseless Schroedinger evolution; a configuration that asks for a noise
-type is accepted as a value object (so user code that builds configs keeps working) but ``TorchEmulator`` raises
-``NotImplementedError`` when it would have to simulate it (open-system / noise paths
-are a later row).
+The hot path this backend accelerates is the Schroedinger evolution.  Stochastic noise ("doppler", "amplitude",
+"SPAM") perturbs the sampled coefficients / the measurement only, so ``TorchEmulator`` runs its realisations as a batch
+of trajectories; noise types that need collapse operators ("dephasing", "relaxation", "depolarizing", "eff_noise") are
+accepted as value objects (user code that builds configs keeps working) but raise ``NotImplementedError`` when they
+would have to be simulated (the master-equation path is a later row).
 """
 from __future__ import annotations
 

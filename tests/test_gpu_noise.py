@@ -1,0 +1,109 @@
+"""Noisy runs on the native backend (``pulser_diff/backend.py:531-611``): every stochastic realisation is one more
+trajectory of ONE batched solver call; measurements are drawn on the GPU.  The draws cannot be matched to the
+reference's RNG stream, so the checks are the limits where the answer is known (vanishing noise strength, certain
+preparation failure, pure detection error) and the sampling statistics."""
+from collections import Counter
+
+import numpy as np
+import pytest
+import torch
+
+import pulser_diff_amd as P
+from pulser_diff_amd import pulses as pl
+from pulser_diff_amd.simresults import CoherentResults, NoisyResults
+from pulser_diff_amd.solver import SolverType
+from pulser_diff_amd.utils import DiagonalObservable, total_magnetization_diag
+
+pytestmark = pytest.mark.gpu
+
+
+def _sequence(n=3):
+    reg = pl.Register.rectangle(1, n, spacing=8, prefix="q")
+    seq = pl.Sequence(reg, pl.MockDevice)
+    seq.declare_channel("g", "rydberg_global")
+    seq.add(pl.Pulse(pl.BlackmanWaveform(300, 2.4), pl.RampWaveform(300, -3.0, 2.0), 0.0), "g")
+    return seq
+
+
+TIMES = [0.01 * k for k in range(1, 31)]  # KRYLOV_SE freezes H at the right end of every interval: resolve the pulse
+
+
+def _z_from_counts(counter, n):
+    tot = sum(counter.values())
+    return sum(c * sum(1.0 if ch == "1" else -1.0 for ch in bits) for bits, c in counter.items()) / tot
+
+
+def test_vanishing_doppler_noise_reproduces_the_coherent_distribution(cuda_device):
+    n = 3
+    seq = _sequence(n)
+    times = [0.1, 0.2, 0.3]
+    clean = P.TorchEmulator.from_sequence(seq, evaluation_times=times).run(solver=SolverType.KRYLOV_SE)
+    z = DiagonalObservable(total_magnetization_diag(n))
+    z_clean = clean.expect([z])[0].real.cpu().numpy()
+    cfg = P.SimConfig(noise="doppler", temperature=0.0, runs=12, samples_per_run=800)
+    torch.manual_seed(11)
+    sim = P.TorchEmulator.from_sequence(seq, config=cfg, evaluation_times=times)
+    sim._noisy_state_budget = 5 * 4 * 8 * 16  # 5 realisations per batch: three solver calls for the 12 runs
+    res = sim.run(solver=SolverType.KRYLOV_SE)
+    assert isinstance(res, NoisyResults) and res.n_measures == 12 * 800 and len(res) == len(z_clean)
+    z_noisy = res.expect([z])[0].numpy()
+    assert z_noisy[0] == -n and res.results[0] == Counter({"0" * n: 1.0})  # t = 0: all atoms in the ground state
+    assert np.abs(z_noisy - z_clean).max() < 5 * np.sqrt(n) / np.sqrt(12 * 800)  # 5 sigma of the sampling error
+    p_clean = (clean.states[-1, :, 0].abs() ** 2).cpu().numpy()[::-1]  # bitstring order: '1' = Rydberg
+    p_noisy = np.array([res.results[-1].get(np.binary_repr(i, n), 0.0) for i in range(2**n)])
+    assert np.abs(p_noisy - p_clean).max() < 5 * 0.5 / np.sqrt(12 * 800)
+    assert sum(res.sample_final_state(100).values()) == 100
+
+
+def test_thermal_detuning_and_beam_profile_change_the_dynamics(cuda_device):
+    n = 3
+    seq = _sequence(n)
+    z = DiagonalObservable(total_magnetization_diag(n))
+    clean = P.TorchEmulator.from_sequence(seq, evaluation_times=TIMES).run(solver=SolverType.KRYLOV_SE)
+    z_clean = clean.expect([z])[0].real[-1].item()
+    torch.manual_seed(2)
+    cfg = P.SimConfig(noise=("doppler", "amplitude"), temperature=5000.0, laser_waist=10.0, amp_sigma=0.2, runs=40, samples_per_run=100)
+    res = P.TorchEmulator.from_sequence(seq, config=cfg, evaluation_times=TIMES).run(solver=SolverType.KRYLOV_SE)
+    z_noisy = res.expect([z])[0][-1].item()
+    assert abs(z_noisy - z_clean) > 0.15  # 6 rad/us of detuning spread and a 0.53 edge-atom amplitude are not a small effect
+    # deterministic part of the amplitude noise alone (no fluctuation): a coherent run with per-atom amplitudes
+    cfg2 = P.SimConfig(noise="amplitude", laser_waist=10.0, amp_sigma=0.0)
+    res2 = P.TorchEmulator.from_sequence(seq, config=cfg2, evaluation_times=TIMES).run(solver=SolverType.KRYLOV_SE)
+    assert isinstance(res2, CoherentResults)
+    ham = P.TorchEmulator.from_sequence(seq, config=cfg2)._hamiltonian
+    assert ham.amp_masks == (1, 2, 4)
+    assert abs((ham.amp_tables[0, 0, 150] / ham.amp_tables[0, 1, 150]).real.item() - np.exp(-0.64)) < 1e-12
+
+
+def test_preparation_and_detection_errors(cuda_device):
+    n = 3
+    seq = _sequence(n)
+    # every atom badly prepared: nothing couples to the light, only '000' is ever measured (no detection error)
+    cfg = P.SimConfig(noise="SPAM", eta=1.0, epsilon=0.0, epsilon_prime=0.0, runs=6, samples_per_run=10)
+    res = P.TorchEmulator.from_sequence(seq, config=cfg, evaluation_times=TIMES).run(solver=SolverType.KRYLOV_SE)
+    assert isinstance(res, NoisyResults) and res.results[-1] == Counter({"000": 1.0}) and res.n_measures == 60
+    # same, with false positives: each measured 0 becomes 1 with probability epsilon
+    torch.manual_seed(4)
+    cfg = P.SimConfig(noise="SPAM", eta=1.0, epsilon=0.2, epsilon_prime=0.0, runs=10, samples_per_run=400)
+    res = P.TorchEmulator.from_sequence(seq, config=cfg, evaluation_times=TIMES).run(solver=SolverType.KRYLOV_SE)
+    ones = sum(p * bits.count("1") for bits, p in res.results[-1].items()) / n
+    assert abs(ones - 0.2) < 5 * np.sqrt(0.2 * 0.8 / (4000 * n))
+    # no preparation error: a coherent result whose samples carry the detection errors (simresults.py:497-540)
+    cfg = P.SimConfig(noise="SPAM", eta=0.0, epsilon=0.0, epsilon_prime=1.0)
+    res = P.TorchEmulator.from_sequence(seq, config=cfg, evaluation_times=TIMES).run(solver=SolverType.KRYLOV_SE)
+    assert isinstance(res, CoherentResults)
+    np.random.seed(1)
+    assert res.sample_final_state(200) == Counter({"000": 200})  # every detected Rydberg atom is lost
+    # partial preparation failure: runs are grouped by configuration of bad atoms (backend.py:551-569)
+    torch.manual_seed(9)
+    cfg = P.SimConfig(noise="SPAM", eta=0.5, epsilon=0.0, epsilon_prime=0.0, runs=30, samples_per_run=50)
+    res = P.TorchEmulator.from_sequence(seq, config=cfg, evaluation_times=TIMES).run(solver=SolverType.KRYLOV_SE)
+    assert sum(res[-1].bitstring_counts.values()) == 1500
+    z_half = _z_from_counts(res[-1].bitstring_counts, n)
+    clean = P.TorchEmulator.from_sequence(seq, evaluation_times=TIMES).run(solver=SolverType.KRYLOV_SE)
+    z_clean = clean.expect([DiagonalObservable(total_magnetization_diag(n))])[0].real[-1].item()
+    assert -n <= z_half < z_clean  # dark atoms stay in the ground state
+    with pytest.raises(NotImplementedError, match="initial state different from the ground"):
+        sim = P.TorchEmulator.from_sequence(seq, config=cfg)
+        sim.set_initial_state(torch.ones(2**n, dtype=torch.complex128) / np.sqrt(2**n))
+        sim.run(solver=SolverType.KRYLOV_SE)
