@@ -22,7 +22,7 @@ import numpy as np
 import torch
 from torch import Tensor
 
-from . import pulses
+from . import pulser_adapter, pulses
 from .hamiltonian import Hamiltonian
 from .result import SampledResult
 from .simconfig import SimConfig
@@ -46,8 +46,10 @@ class TorchEmulator:
 
     def __init__(self, sampled_seq, register, device, sampling_rate: float = 1.0, config: Optional[SimConfig] = None,
                  evaluation_times: Union[float, str, Any] = "Full", compute_device: Union[str, torch.device] = "cuda") -> None:
-        if not isinstance(sampled_seq, pulses.SequenceSamples):
-            raise TypeError("The provided sequence has to be a valid " "SequenceSamples instance.")
+        # real Pulser objects are converted by attribute access (pulser_adapter.py); anything else is a TypeError
+        sampled_seq = pulser_adapter.adapt_samples(sampled_seq)
+        register = pulser_adapter.adapt_register(register)
+        device = pulser_adapter.adapt_device(device)
         if sampled_seq.max_duration == 0:
             raise ValueError("SequenceSamples is empty.")
         device.validate_register(register)
@@ -381,7 +383,9 @@ class TorchEmulator:
                       evaluation_times: Union[float, str, Any] = "Full", with_modulation: bool = False,
                       compute_device: Union[str, torch.device] = "cuda") -> "TorchEmulator":
         r"""backend.py:651-711."""
-        if not isinstance(sequence, pulses.Sequence):
+        native = isinstance(sequence, pulses.Sequence)
+        if not native and not all(hasattr(sequence, a) for a in ("is_parametrized", "is_register_mappable", "_schedule",
+                                                                   "declared_channels", "get_duration", "register", "device")):
             raise TypeError("The provided sequence has to be a valid pulser.Sequence instance.")
         if sequence.is_parametrized() or sequence.is_register_mappable():
             raise ValueError(
@@ -396,7 +400,8 @@ class TorchEmulator:
             raise NotImplementedError(
                 "Simulation of sequences combining an SLM mask and output " "modulation is not supported."
             )
+        sampler = pulses.sample if native else pulser_adapter.sample_pulser_sequence  # the latter needs Pulser installed
         return cls(
-            pulses.sample(sequence, modulation=with_modulation,
-                          extended_duration=sequence.get_duration(include_fall_time=with_modulation)),
+            sampler(sequence, modulation=with_modulation,
+                    extended_duration=sequence.get_duration(include_fall_time=with_modulation)),
             sequence.register, sequence.device, sampling_rate, config, evaluation_times, compute_device=compute_device)

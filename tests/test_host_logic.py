@@ -220,3 +220,55 @@ def test_solver_options_mapping():
     assert tolerance_from_options({"atol": 1e-10, "rtol": 1e-8}) == pytest.approx(1e-12)
     with pytest.raises(TypeError):
         tolerance_from_options({"bogus": 1})
+
+
+def test_pulser_objects_are_adapted_by_attribute_access():
+    """objects shaped like pulser's SequenceSamples / Register / Device (same attribute names,
+    arrays wrapped like pulser.math.AbstractArray) give the same structured Hamiltonian as the native containers."""
+    from types import SimpleNamespace
+
+    import numpy as np
+
+    from pulser_diff_amd import pulser_adapter as A
+
+    class FakeAbstractArray:  # pulser.math.AbstractArray: wraps ndarray or tensor, as_tensor() keeps autograd history
+        def __init__(self, a):
+            self._array = a
+
+        def as_tensor(self):
+            return self._array if isinstance(self._array, torch.Tensor) else torch.as_tensor(self._array)
+
+    reg = pl.Register.rectangle(1, 3, spacing=8, prefix="q")
+    seq = pl.Sequence(reg, pl.MockDevice)
+    seq.declare_channel("g", "rydberg_global")
+    seq.declare_channel("l", "rydberg_local", initial_target="q1")
+    omega = torch.tensor(3.0, dtype=torch.float64, requires_grad=True)
+    seq.add(pl.Pulse.ConstantPulse(100, omega, 1.0, 0.2), "g")
+    seq.add(pl.Pulse.ConstantPulse(60, 2.0, 0.0, 0.0), "l")
+    native = pl.sample(seq)
+    fake = SimpleNamespace(
+        channels=list(native.channels),
+        samples_list=[SimpleNamespace(amp=FakeAbstractArray(cs.amp), det=FakeAbstractArray(cs.det.detach().numpy()),
+                                      phase=FakeAbstractArray(cs.phase.detach().numpy()),
+                                      slots=[SimpleNamespace(ti=s.ti, tf=s.tf, targets=set(s.targets)) for s in cs.slots])
+                      for cs in native.samples_list],
+        _ch_objs={k: SimpleNamespace(addressing=v.addressing, basis=v.basis) for k, v in native._ch_objs.items()},
+        _slm_mask=SimpleNamespace(targets=set(), end=0), _magnetic_field=None, _measurement=None)
+    fake_reg = SimpleNamespace(qubits={k: FakeAbstractArray(v.numpy()) for k, v in reg.qubits.items()}, qubit_ids=reg.qubit_ids)
+    fake_dev = SimpleNamespace(name="FakeAnalog", interaction_coeff=pl.MockDevice.interaction_coeff,
+                               supported_bases={"ground-rydberg"}, supports_slm_mask=False, max_atom_num=2)
+    with pytest.raises(ValueError, match="exceeds the device maximum"):
+        P.TorchEmulator(fake, fake_reg, fake_dev, compute_device="cpu")
+    fake_dev.max_atom_num = 10
+    a = P.TorchEmulator(fake, fake_reg, fake_dev, compute_device="cpu")._hamiltonian
+    b = P.TorchEmulator(native, reg, pl.MockDevice, compute_device="cpu")._hamiltonian
+    assert a.amp_masks == b.amp_masks and a.det_masks == b.det_masks
+    assert torch.equal(a.amp_tables.detach(), b.amp_tables.detach()) and torch.equal(a.det_tables, b.det_tables)
+    assert torch.equal(a.u_pairs, b.u_pairs)
+    a.amp_tables.abs().sum().backward()  # autograd history survives the adapter (as_tensor path)
+    assert omega.grad is not None and omega.grad.item() > 0
+    assert isinstance(A.adapt_device(fake_dev), pl.Device) and A.adapt_samples(native) is native
+    with pytest.raises(TypeError):
+        A.adapt_register(object())
+    with pytest.raises(TypeError):
+        P.TorchEmulator.from_sequence(SimpleNamespace(register=reg))
