@@ -14,7 +14,9 @@ qubits 0..g-1 — select the GPU, each rank owns a contiguous slab of 2^(N-g) am
 
 Scalars (<psi|O|psi>, norms) are reduced with one small all_reduce.  The local pass is the native
 ``rydiff_apply_factor`` kernel; the exchange is bandwidth-bound on xGMI (32 MiB per partner per pass at N=24, G=8), so the
-roofline of this mode is the link, not HBM.  Forward only (KRYLOV_SE map) in this round.
+roofline of this mode is the link, not HBM.  KRYLOV_SE map; gradients w.r.t. the coefficient tables
+and the pair interactions come from ``grad_virtual`` / ``grad_distributed`` (exact discrete adjoint: the same factor passes
+with conjugated scalars on the cotangent slabs, per-rank partial contractions, one all_reduce of the tiny gradient arrays).
 
 Two drivers share one code path: ``run_distributed`` (one process per GPU) and ``run_virtual`` (all G "ranks" inside one
 process on one device — how the algorithm is tested against the single-GPU solver on a 1-GPU box).
@@ -201,7 +203,8 @@ class ShardedPlan:
 class NativeOps:
     """Local factor pass through the C ABI (``rydiff_apply_factor``)."""
 
-    def __init__(self, plan: ShardedPlan, device: torch.device):
+    def __init__(self, plan: ShardedPlan, device: torch.device, interactions: bool = True):
+        """``interactions=False``: no pair interactions in the local diagonal (used to form pure flip sums F_k mu)."""
         from . import _native
 
         self._native = _native
@@ -211,7 +214,8 @@ class NativeOps:
         prob = plan.prob
         self.amp_masks = np.asarray(plan.local_amp_masks, dtype=np.uint32)
         self.det_masks = np.asarray(list(plan.local_det_masks) + plan.extra_det_masks, dtype=np.uint32)
-        self.u_local = torch.as_tensor(prob.local_u_pairs(), dtype=torch.float64, device=device)
+        u_loc = prob.local_u_pairs()
+        self.u_local = torch.as_tensor(u_loc if interactions else np.zeros_like(u_loc), dtype=torch.float64, device=device)
         self.dim = 1 << prob.n_local
         self.workspace = torch.empty(8 * self.dim + 256, dtype=torch.uint8, device=device)
         self._diag_ready = False
@@ -314,3 +318,212 @@ def run_distributed(prob: ShardedProblem, psi0_local: Tensor, tsave, group=None,
             x, y = y, x
         measure()
     return x, (torch.stack(expect) if expect else None)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# gradients: exact discrete adjoint of the sharded factor chain
+# ---------------------------------------------------------------------------------------------------------------------
+class _VirtualFabric:
+    """All ranks in this process: a partner's slab is just another list entry."""
+
+    def __init__(self, prob: ShardedProblem):
+        self.ranks = list(range(prob.world))
+
+    def exchange(self, vecs: list, partners_of: Callable) -> list:
+        return [[vecs[p] for p in partners_of(r)] for r in self.ranks]
+
+    def allreduce_(self, t: Tensor) -> Tensor:
+        return t
+
+
+class _DistFabric:
+    """One process per GPU: hypercube P2P exchange (one xGMI link per partner) + all_reduce of scalars / tiny arrays."""
+
+    def __init__(self, prob: ShardedProblem, group=None):
+        import torch.distributed as dist
+
+        self._dist, self.group = dist, group
+        self.rank, world = dist.get_rank(group), dist.get_world_size(group)
+        if world != prob.world:
+            raise ValueError(f"world size {world} != 2^{prob.n_gpu_bits}")
+        self.ranks = [self.rank]
+
+    def exchange(self, vecs: list, partners_of: Callable) -> list:
+        dist, x = self._dist, vecs[0]
+        partners = partners_of(self.rank)
+        recv = [torch.empty_like(x) for _ in partners]
+        reqs = []
+        for buf, partner in zip(recv, partners):
+            reqs.append(dist.P2POp(dist.isend, x, partner, self.group))
+            reqs.append(dist.P2POp(dist.irecv, buf, partner, self.group))
+        if reqs:
+            for w in dist.batch_isend_irecv(reqs):
+                w.wait()
+        return [recv]
+
+    def allreduce_(self, t: Tensor) -> Tensor:
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+        return t
+
+
+def _value_and_grad(prob: ShardedProblem, tsave, fabric, psi_slabs: list, obs_slabs: list, grad_expect,
+                    ops_factory: Optional[Callable]) -> dict:
+    """Forward with a tape of every factor input (slab-sized entries), then the reverse sweep.
+
+    Loss: L = sum_k grad_expect[k] * <psi(t_k)|O|psi(t_k)> for the diagonal observable O.  Per factor
+    y = (gamma + beta H) x with cotangent mu (dL = Re<mu, dy>):
+      dL/d(diagonal weight w) = sum_x w(x) r(x),  r = Re(beta conj(mu) x)         -> detuning terms, pair interactions
+      dL/dRe c = Re(beta z1), dL/dIm c = Im(beta z2),  z1 = <F mu, x>, z2 = <F_signed mu, x>   -> amplitude terms
+    where the flips of the local qubits are formed by a local pass without diagonal (F_k mu), and the flip of a GPU qubit is
+    the partner rank's cotangent slab, i.e. a plain inner product.  mu <- (conj(gamma) + conj(beta) H) mu is the forward pass
+    with conjugated scalars (H is Hermitian).  Contractions are per-rank partial sums; the gradient arrays are all-reduced."""
+    plan = ShardedPlan(prob, np.asarray(tsave), _design_native)
+    g, nl = prob.n_gpu_bits, prob.n_local
+    dloc = 1 << nl
+    device = psi_slabs[0].device
+    make = ops_factory or NativeOps
+    ops = [make(plan, device) for _ in fabric.ranks]
+    flat = [make(plan, device, interactions=False) for _ in fabric.ranks]
+
+    def partners_of(r: int) -> list:
+        return [r ^ (1 << (g - 1 - q)) for q in range(g)]
+
+    T = len(plan.tsave) - 1
+    gexp = np.asarray(grad_expect, dtype=np.float64)
+    if gexp.shape != (T + 1,):
+        raise ValueError("grad_expect must have one entry per tsave")
+
+    # ---- forward, keeping every factor input
+    xs = [p.clone() for p in psi_slabs]
+    tape, step_calls, expect = [], [], []
+
+    def measure() -> None:
+        e = sum((o * (x.real**2 + x.imag**2)).sum() for o, x in zip(obs_slabs, xs)).reshape(1)
+        expect.append(fabric.allreduce_(e)[0])
+
+    measure()
+    for k in range(T):
+        calls = [plan.calls_for_step(k, r) for r in fabric.ranks]
+        step_calls.append(calls)
+        for i in range(len(calls[0])):
+            rem = fabric.exchange(xs, partners_of)
+            tape.append(xs)
+            ys = [torch.empty_like(x) for x in xs]
+            for j in range(len(fabric.ranks)):
+                ops[j].apply(calls[j][i], xs[j], rem[j], ys[j])
+            xs = ys
+        measure()
+
+    # ---- reverse sweep
+    ns = prob.amp_tables.shape[1] if prob.amp_tables.size else prob.det_tables.shape[1]
+    ka, kd = len(prob.amp_masks), len(prob.det_masks)
+    g_amp = np.zeros((ka, ns), dtype=np.complex128)
+    g_det = np.zeros((kd, ns), dtype=np.float64)
+    idx = torch.arange(dloc, device=device)
+    occ = torch.stack([1.0 - ((idx >> (nl - 1 - a)) & 1).to(torch.float64) for a in range(nl)]) if nl else torch.zeros(0, dloc)
+    det_occ = [sum((occ[q - g] for q in range(g, prob.n_qubits) if m >> q & 1), torch.zeros(dloc, dtype=torch.float64, device=device))
+               for m in prob.det_masks]
+    wtot = [torch.zeros(dloc, dtype=torch.float64, device=device) for _ in fabric.ranks]
+    n_loc_terms = len(plan.amp_src)
+    zero_det = np.zeros(len(plan.local_det_masks) + nl)
+    unit_calls = [(FactorCall(np.eye(n_loc_terms, dtype=complex)[li], zero_det, 0.0 + 0.0j, 1.0 + 0.0j, [], []),
+                   FactorCall(1j * np.eye(n_loc_terms, dtype=complex)[li], zero_det, 0.0 + 0.0j, 1.0 + 0.0j, [], []))
+                  for li in range(n_loc_terms)]
+    mus = [2.0 * gexp[T] * o * x for o, x in zip(obs_slabs, xs)]
+    scratch = [torch.empty_like(x) for x in xs]
+    fidx = len(tape)
+    for k in reversed(range(T)):
+        calls = step_calls[k]
+        acc_loc = np.zeros(n_loc_terms, dtype=np.complex128)  # (dL/dRe c, dL/dIm c) of the local part of each term
+        acc_q = np.zeros(g, dtype=np.complex128)               # same for the flip of each GPU qubit
+        rsum = [torch.zeros(dloc, dtype=torch.float64, device=device) for _ in fabric.ranks]
+        for i in reversed(range(len(calls[0]))):
+            fidx -= 1
+            x_in = tape[fidx]
+            rem = fabric.exchange(mus, partners_of)
+            new_mus = []
+            for j, r in enumerate(fabric.ranks):
+                c, mu, x = calls[j][i], mus[j], x_in[j]
+                beta = complex(c.beta)
+                rsum[j] += (beta * mu.conj() * x).real
+                for q in range(g):
+                    z1 = complex(torch.vdot(rem[j][q], x))
+                    sgn = 1.0 if (r >> (g - 1 - q)) & 1 else -1.0
+                    acc_q[q] += complex((beta * z1).real, (beta * sgn * z1).imag)
+                for li, (call_re, call_im) in enumerate(unit_calls):
+                    z1 = complex(torch.vdot(flat[j].apply(call_re, mu, [], scratch[j]), x))
+                    z2 = complex(torch.vdot(-1j * flat[j].apply(call_im, mu, [], scratch[j]), x))
+                    acc_loc[li] += complex((beta * z1).real, (beta * z2).imag)
+                adj = FactorCall(c.c_amp, c.c_det, np.conj(c.gamma), np.conj(beta),
+                                 [np.conj(beta) * (rc / beta) for rc in c.remote_coef], c.partners)
+                new_mus.append(ops[j].apply(adj, mu, rem[j], torch.empty_like(mu)))
+            mus = new_mus
+        # this interval's exponential is complete: coefficient gradients -> table entries (interpolation weights at t_{k+1})
+        g_term = np.zeros(ka, dtype=np.complex128)
+        for li, src in enumerate(plan.amp_src):
+            g_term[src] += acc_loc[li]
+        for kk, m in enumerate(prob.amp_masks):
+            g_term[kk] += sum(acc_q[q] for q in range(g) if m >> q & 1)
+        g_dterm = np.zeros(kd)
+        for j, r in enumerate(fabric.ranks):
+            rocc = prob.rank_occupation(r)
+            rtot = float(rsum[j].sum())
+            for kk, m in enumerate(prob.det_masks):
+                g_dterm[kk] += 2.0 * (float((rsum[j] * det_occ[kk]).sum()) + rtot * sum(rocc[q] for q in range(g) if m >> q & 1))
+            wtot[j] += rsum[j]
+        t = float(plan.tsave[k + 1])
+        i1 = max(int(min(math.floor(t / prob.dt), ns - 2)), 0)
+        i2 = min(i1 + 1, ns - 2)
+        frac = (t - i1 * prob.dt) / prob.dt
+        for arr, gt in ((g_amp, g_term), (g_det, g_dterm)):
+            if arr.shape[0]:
+                arr[:, i1] += (1.0 - frac) * gt
+                arr[:, i2] += frac * gt
+        if gexp[k] != 0.0:
+            mus = [mu + 2.0 * gexp[k] * o * x for mu, o, x in zip(mus, obs_slabs, tape[fidx])]
+
+    # ---- pair interactions: g_U[i,j] = sum_x n_i n_j wtot[x]
+    n = prob.n_qubits
+    g_u = np.zeros(n * (n - 1) // 2)
+    for j, r in enumerate(fabric.ranks):
+        rocc = prob.rank_occupation(r)
+        wsum = float(wtot[j].sum())
+        ow = occ * wtot[j]                      # [nl, dloc]
+        pair = (ow @ occ.T).cpu().numpy() if nl else np.zeros((0, 0))
+        single = ow.sum(1).cpu().numpy() if nl else np.zeros(0)
+        for a, b in itertools.combinations(range(n), 2):
+            if b < g:
+                v = rocc[a] * rocc[b] * wsum
+            elif a < g:
+                v = rocc[a] * single[b - g]
+            else:
+                v = pair[a - g, b - g]
+            g_u[_pair_index(n, a, b)] += v
+    packed = torch.as_tensor(np.concatenate([g_amp.real.ravel(), g_amp.imag.ravel(), g_det.ravel(), g_u]), device=device)
+    packed = fabric.allreduce_(packed).cpu().numpy()
+    na = ka * ns
+    g_amp = (packed[:na] + 1j * packed[na:2 * na]).reshape(ka, ns)
+    g_det = packed[2 * na:2 * na + kd * ns].reshape(kd, ns)
+    g_u = packed[2 * na + kd * ns:]
+    return {"final": xs, "expect": torch.stack(expect), "g_amp": g_amp, "g_det": g_det, "g_u": g_u, "g_psi0": mus}
+
+
+def grad_virtual(prob: ShardedProblem, psi0: Tensor, tsave, obs_diag: Tensor, grad_expect,
+                 ops_factory: Optional[Callable] = None) -> dict:
+    """All G ranks inside this process: value and gradients of L = sum_k grad_expect[k] <O>(t_k).  Returns expect [n_t],
+    g_amp [K_a, n] (dL/dRe + i dL/dIm), g_det [K_d, n], g_u [pairs], final / g_psi0 (2^N,)."""
+    dloc = 1 << prob.n_local
+    fabric = _VirtualFabric(prob)
+    out = _value_and_grad(prob, tsave, fabric, [psi0[r * dloc:(r + 1) * dloc] for r in fabric.ranks],
+                          [obs_diag[r * dloc:(r + 1) * dloc] for r in fabric.ranks], grad_expect, ops_factory)
+    out["final"], out["g_psi0"] = torch.cat(out["final"]), torch.cat(out["g_psi0"])
+    return out
+
+
+def grad_distributed(prob: ShardedProblem, psi0_local: Tensor, tsave, obs_diag_local: Tensor, grad_expect, group=None,
+                     ops_factory: Optional[Callable] = None) -> dict:
+    """One process per GPU: same as ``grad_virtual`` with this rank's slabs; the gradient arrays are identical on all ranks."""
+    fabric = _DistFabric(prob, group)
+    out = _value_and_grad(prob, tsave, fabric, [psi0_local], [obs_diag_local], grad_expect, ops_factory)
+    out["final"], out["g_psi0"] = out["final"][0], out["g_psi0"][0]
+    return out
