@@ -185,7 +185,8 @@ class _RydbergEvolve(torch.autograd.Function):
         ctx.has_obs = obs_c is not None
         ctx.set_materialize_grads(False)
         ctx.stats = {"degree": info.degree, "total_factors": info.total_factors, "rho": info.rho_design,
-                     "spectral": (info.spectral_lo, info.spectral_hi)}
+                     "spectral": (info.spectral_lo, info.spectral_hi), "n_stages": info.n_stages,
+                     "tape": ("none", "steps", "full")[need_tape]}
         spec.options["_last_stats"] = ctx.stats
         return states, expect
 

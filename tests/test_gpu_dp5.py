@@ -112,3 +112,34 @@ def test_time_derivative_equals_heisenberg_rate(cuda_device):
         o = torch.diag(zdiag.to(torch.complex128))
         rate = (1j * (st[k].conj() @ ((h @ o - o @ h) @ st[k]))).real
         assert abs(g[k].item() - rate.item()) < 1e-6 * max(1.0, abs(rate.item()))
+
+
+@pytest.mark.parametrize("n_qubits,tape", [(13, "steps"), (15, "full")])
+def test_continuous_solver_on_chained_tile_kernels_matches_direct_kernels(cuda_device, n_qubits, tape):
+    """DP5_SE on registers that take the chained LDS-tile path: several Magnus exponentials (stages) per tsave interval,
+    cut at the sample grid, with either tape mode — states, expectation values and all gradients (tables, U_ij,
+    evaluation times) against the one-amplitude-per-thread kernels."""
+    from pulser_diff_amd import _native
+
+    terms = random_terms(n_qubits, 9, 0.004, seed=500 + n_qubits, local=True)
+    tsave0 = torch.tensor([0.0, 0.0031, 0.0105, 0.0162, 0.0290], dtype=torch.float64)
+    psi0 = R.all_ground_state(n_qubits).T.contiguous().to(cuda_device)
+    obs = R.total_magnetization_diag(n_qubits)[None].to(cuda_device)
+    w = torch.tensor([0.3, -0.2, 0.9, 0.1, 1.4], dtype=torch.float64, device=cuda_device)
+    out = {}
+    for variant in (1, 0):
+        _native.set_kernel_variant(variant)
+        try:
+            amp, det, u, spec = to_native(terms, cuda_device, SolverType.DP5_SE, store_states=False)
+            spec.tape = tape
+            ts = tsave0.clone().requires_grad_(True)
+            for t in (amp, det, u):
+                t.requires_grad_(True)
+            _, expect = evolve(amp, det, u, ts, psi0, spec, obs)
+            (expect[0, :, 0] * w).sum().backward()
+            out[variant] = [expect.detach().cpu(), amp.grad.cpu(), det.grad.cpu(), u.grad.cpu(), ts.grad.cpu()]
+            assert spec.options["_last_stats"]["n_stages"] > len(tsave0) - 1  # more than one exponential per interval
+        finally:
+            _native.set_kernel_variant(0)
+    for name, ref, got in zip(("expect", "amp", "det", "u", "tsave"), out[1], out[0]):
+        assert rel_err(got.numpy(), ref.numpy()) < 1e-10, name
