@@ -606,6 +606,45 @@ __global__ void k_scatter_grads(ScatterArgs a) {
 #include "chain_kernels.hpp"
 #include "persist_kernels.hpp"
 static_assert(sizeof(PersistFactor) == 48, "plan.hpp sizes the factor table with 48 bytes per entry");
+
+// ---- chained tile passes (chain_kernels.hpp) ------------------------------------------------------------------------
+// Tile layouts: every layout keeps a contiguous low run of >= 2^3 amplitudes so that global accesses stay coalesced.
+//   two layouts   (13 <= N <= 22):  A = [0,12)            B = [0,24-N) u [12,N)
+//   three layouts (23 <= N <= 28):  A = [0,12)            B = [0,4) u [12,20)        C = [0,32-N) u [20,N)
+// With three layouts a factor takes two launches (start in A or C, middle pass in B, finish in C or A — the finishing
+// launch also starts the next factor), 4R+3W instead of 2R+2W: still far better than 16-byte runs in a two-layout B.
+struct LayoutDesc {
+    int lo, hs, hb;
+    uint32_t bits;  // amplitude-index bits covered by the tile
+};
+
+static int g_force_three_layouts = 0;  // kernel variant 7: three layouts wherever they are legal (A/B tests)
+
+int chain_layout_count(int N) {
+    if (N >= 23 || (g_force_three_layouts && N >= 21)) return 3;
+    return 2;
+}
+
+LayoutDesc chain_layout(int N, int which) {
+    LayoutDesc d{};
+    const bool three = chain_layout_count(N) == 3;
+    if (which == 0) {  // A
+        d.lo = kTileBits;
+        d.hs = kTileBits;
+        d.hb = 0;
+    } else if (which == 1) {  // B
+        d.hs = kTileBits;
+        d.hb = three ? 8 : N - kTileBits;
+        d.lo = kTileBits - d.hb;
+    } else {  // C (three-layout mode only)
+        d.hs = 20;
+        d.hb = N - 20;
+        d.lo = kTileBits - d.hb;
+    }
+    d.bits = ((1u << d.lo) - 1u) | (((1u << d.hb) - 1u) << d.hs);
+    return d;
+}
+
 #include "chain2_kernels.hpp"
 
 // ------------------------------------------------------------------------------------------------
@@ -791,15 +830,15 @@ int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_
     } else {
         HIP_TRY(hipMemsetAsync(udiag, 0, pl.dim * sizeof(double), stream));
     }
-    if (pl.N > 12 && pl.N <= 24) {  // split diagonal for the two tile layouts of the chained passes
+    if (pl.N > 12 && pl.N <= 28) {  // split diagonal for the tile layouts of the chained passes
         const unsigned tiles = unsigned(pl.dim >> 12);
         double* split = reinterpret_cast<double*>(ws + pl.off_split);
         const size_t per_layout = 4096 + size_t(tiles) * 16;
-        const int lay[2][3] = {{12, 12, 0}, {24 - pl.N, 12, pl.N - 12}};  // (lo, hs, hb) of layouts A and B
-        for (int l = 0; l < 2; ++l) {
+        for (int l = 0; l < chain_layout_count(pl.N); ++l) {
+            const LayoutDesc d = chain_layout(pl.N, l);
             double* utt = split + l * per_layout;
             hipLaunchKernelGGL(k_build_split, dim3((4096 + tiles + 255) / 256), dim3(256), 0, stream, utt, utt + 4096,
-                               p->u_pairs, pl.N, lay[l][0], lay[l][1], lay[l][2], tiles);
+                               p->u_pairs, pl.N, d.lo, d.hs, d.hb, tiles);
             LAUNCH_CHECK();
         }
     }
@@ -867,26 +906,31 @@ int launch_factor(const Runtime& rt, char* ws, const double2* xin, double2* xout
     return RYDIFF_OK;
 }
 
-// ---- chained two-layout passes (chain_kernels.hpp) ---------------------------------------------------------------
-struct LayoutDesc {
-    int lo, hs, hb;
-    uint32_t bits;  // amplitude-index bits covered by the tile
+// ---- chained tile passes: launch schedule (layouts are defined next to the kernel includes) ------------------------
+// One launch of a chain: which layout, which index bits the partial already covers, which factor's partial it extends
+// (`fin`, -1: none; `completes`: the factor is complete afterwards) and which factor it starts (`sta`, -1: none).
+struct KernelStep {
+    int layout;
+    uint32_t covered;
+    int fin;
+    bool completes;
+    int sta;
 };
 
-LayoutDesc chain_layout(int N, int which) {
-    LayoutDesc d{};
-    if (which == 0) {  // A
-        d.lo = kTileBits;
-        d.hs = kTileBits;
-        d.hb = 0;
-        d.bits = (1u << kTileBits) - 1u;
-    } else {  // B
-        d.hb = N - kTileBits;
-        d.hs = kTileBits;
-        d.lo = 2 * kTileBits - N;
-        d.bits = ((1u << d.lo) - 1u) | (((1u << d.hb) - 1u) << kTileBits);
+void chain_schedule(int N, int F, std::vector<KernelStep>& ks) {
+    ks.clear();
+    if (chain_layout_count(N) == 2) {
+        for (int k = 0; k <= F; ++k)
+            ks.push_back({k & 1, k > 0 ? chain_layout(N, (k - 1) & 1).bits : 0u, k - 1, true, k < F ? k : -1});
+        return;
     }
-    return d;
+    const uint32_t bbits = chain_layout(N, 1).bits;
+    auto end_layout = [](int m) { return (m & 1) ? 2 : 0; };  // factor m starts in A (even m) or C (odd m)
+    for (int m = 0; m <= F; ++m) {
+        const uint32_t cov = m > 0 ? (chain_layout(N, end_layout(m - 1)).bits | bbits) : 0u;
+        ks.push_back({end_layout(m), cov, m - 1, true, m < F ? m : -1});
+        if (m < F) ks.push_back({1, chain_layout(N, end_layout(m)).bits, m, false, -1});
+    }
 }
 
 uint32_t to_tile_mask(const LayoutDesc& d, uint32_t index_mask) {
@@ -901,7 +945,7 @@ uint32_t to_tile_mask(const LayoutDesc& d, uint32_t index_mask) {
 bool chain_enabled(const Runtime& rt) {
     const int N = rt.pl.N;
     if (g_kernel_variant == 1 || g_kernel_variant == 5) return false;
-    return N > kTileBits && N <= 2 * kTileBits;
+    return N > kTileBits && N <= 28;
 }
 
 struct ChainStep {
@@ -914,6 +958,7 @@ struct ChainStep {
     FactorScalars fin, sta;
     int has_p, has_q, write_v;
     int layout, prev_layout;
+    uint32_t covered_bits = 0;  // index bits whose flips the incoming partial already contains
     // backward mode
     bool bwd = false;
     const double2* x_fin = nullptr;
@@ -987,7 +1032,7 @@ int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, hipStream_t s
     ca.write_v = cs.write_v;
     ca.ga = pl.ga.n;
     ca.gd = pl.gd.n;
-    const uint32_t prev_bits = cs.prev_layout >= 0 ? chain_layout(pl.N, cs.prev_layout).bits : 0u;
+    const uint32_t prev_bits = cs.covered_bits;
     for (int g = 0; g < pl.ga.n; ++g) {
         ca.fin_mask[g] = to_tile_mask(X, pl.ga.amp_index_mask[g] & ~prev_bits);
         ca.sta_mask[g] = to_tile_mask(X, pl.ga.amp_index_mask[g]);
@@ -1140,31 +1185,39 @@ int run_chain(const Runtime& rt, char* ws, const std::vector<ChainItem>& items, 
               ExpFn exp_slot, bool skip_last_finish, hipStream_t stream) {
     const Plan& pl = rt.pl;
     double2* pp[2] = {reinterpret_cast<double2*>(ws + pl.off_pp0), reinterpret_cast<double2*>(ws + pl.off_pp1)};
-    const int F = int(items.size());
-    const int n_launch = skip_last_finish ? F : F + 1;
+    const int F = int(items.size()) - (skip_last_finish ? 1 : 0);  // the last factor is not even started then
+    if (F <= 0) return RYDIFF_OK;
+    std::vector<KernelStep> ks;
+    chain_schedule(pl.N, F, ks);
     const double2* cur = start;
-    for (int j = 0; j < n_launch; ++j) {
+    for (size_t k = 0; k < ks.size(); ++k) {
+        const KernelStep& st = ks[k];
         ChainStep cs{};
-        cs.layout = j & 1;
-        cs.prev_layout = j > 0 ? ((j - 1) & 1) : -1;
+        cs.layout = st.layout;
+        cs.prev_layout = k > 0 ? ks[k - 1].layout : -1;
+        cs.covered_bits = st.covered;
         cs.u = cur;
-        cs.has_p = j >= 1;
-        cs.has_q = (j < F) && !(skip_last_finish && j == F - 1);
-        cs.p = cs.has_p ? pp[(j - 1) & 1] : nullptr;
-        cs.q_out = cs.has_q ? pp[j & 1] : nullptr;
+        cs.has_p = st.fin >= 0;
+        cs.has_q = st.sta >= 0;
+        cs.p = cs.has_p ? pp[(k - 1) & 1] : nullptr;
+        cs.q_out = cs.has_q ? pp[k & 1] : nullptr;
         cs.write_v = cs.has_p;
-        cs.v_out = cs.has_p ? dst(j - 1) : nullptr;
-        cs.fin_stage = cs.has_p ? items[j - 1].stage : -1;
-        cs.sta_stage = cs.has_q ? items[j].stage : -1;
-        if (cs.has_p) cs.fin = items[j - 1].s;
-        if (cs.has_q) cs.sta = items[j].s;
-        if (cs.has_p && !cs.v_out) return fail(RYDIFF_EINVAL, "internal: chain destination missing");
-        if (cs.has_p) exp_slot(j - 1, cs);
+        if (cs.has_p) {
+            cs.v_out = st.completes ? dst(st.fin) : pp[k & 1];  // a middle pass hands the extended partial on
+            cs.fin_stage = items[st.fin].stage;
+            cs.fin = items[st.fin].s;
+            if (!cs.v_out) return fail(RYDIFF_EINVAL, "internal: chain destination missing");
+            if (st.completes) exp_slot(st.fin, cs);
+        } else {
+            cs.fin_stage = -1;
+        }
+        cs.sta_stage = cs.has_q ? items[st.sta].stage : -1;
+        if (cs.has_q) cs.sta = items[st.sta].s;
         int rc = launch_chain(rt, ws, cs, stream);
         if (rc) return rc;
-        if (cs.has_p) {
+        if (cs.has_p && st.completes) {
             cur = cs.v_out;
-            rc = on_done(j - 1, cs.v_out);
+            rc = on_done(st.fin, cs.v_out);
             if (rc) return rc;
         }
     }
@@ -1210,52 +1263,61 @@ int run_chain_bwd(const Runtime& rt, char* ws, const std::vector<ChainItem>& ite
     const Plan& pl = rt.pl;
     double2* pp[2] = {reinterpret_cast<double2*>(ws + pl.off_pp0), reinterpret_cast<double2*>(ws + pl.off_pp1)};
     const int M = int(items.size());
+    std::vector<KernelStep> ks;
+    chain_schedule(pl.N, M, ks);
     const double2* cur = lam_in;
     // adjoint factor index a = 0..M-1 corresponds to forward factor f = M-1-a
-    for (int j = 0; j <= M; ++j) {
+    for (size_t k = 0; k < ks.size(); ++k) {
+        const KernelStep& st = ks[k];
         ChainStep cs{};
         cs.bwd = true;
-        cs.layout = j & 1;
-        cs.prev_layout = j > 0 ? ((j - 1) & 1) : -1;
+        cs.layout = st.layout;
+        cs.prev_layout = k > 0 ? ks[k - 1].layout : -1;
+        cs.covered_bits = st.covered;
         cs.u = cur;
-        cs.has_p = j >= 1;
-        cs.has_q = j < M;
-        cs.p = cs.has_p ? pp[(j - 1) & 1] : nullptr;
-        cs.q_out = cs.has_q ? pp[j & 1] : nullptr;
+        cs.has_p = st.fin >= 0;
+        cs.has_q = st.sta >= 0;
+        cs.p = cs.has_p ? pp[(k - 1) & 1] : nullptr;
+        cs.q_out = cs.has_q ? pp[k & 1] : nullptr;
         cs.write_v = cs.has_p;
         cs.wtot = wtot;
         if (cs.has_p) {
-            const ChainItem& it = items[M - j];  // forward factor being finished (adjoint index j-1)
+            const int f = M - 1 - st.fin;  // forward factor whose adjoint this launch extends / completes
+            const ChainItem& it = items[f];
             cs.fin_stage = it.stage;
             cs.fin = {it.s.gr, -it.s.gi, it.s.br, -it.s.bi};
             cs.cb_fin_r = it.s.br;
             cs.cb_fin_i = it.s.bi;
-            cs.x_fin = xs[M - j];
-            cl ^= 1;
-            cs.v_out = lam_bufs[cl];
-            if (cs.v_out == cur) return fail(RYDIFF_EINVAL, "internal: cotangent ping-pong clash");
+            cs.x_fin = xs[f];
+            if (st.completes) {
+                cl ^= 1;
+                cs.v_out = lam_bufs[cl];
+                if (cs.v_out == cur) return fail(RYDIFF_EINVAL, "internal: cotangent ping-pong clash");
+            } else {
+                cs.v_out = pp[k & 1];
+            }
         }
         if (cs.has_q) {
-            const ChainItem& it = items[M - 1 - j];
+            const int f = M - 1 - st.sta;
+            const ChainItem& it = items[f];
             cs.sta_stage = it.stage;
             cs.sta = {it.s.gr, -it.s.gi, it.s.br, -it.s.bi};
             cs.cb_sta_r = it.s.br;
             cs.cb_sta_i = it.s.bi;
-            cs.x_sta = xs[M - 1 - j];
-            // the cotangent `cur` (complete after this kernel's finish stage, or lam_in for j = 0) sits at the output of
-            // forward factor M-1-j: report exponential boundaries for dL/dtau
-            const bool stage_end = (j == 0) || (items[M - j].stage != it.stage);
-            if (stage_end && j == 0) {
+            cs.x_sta = xs[f];
+            // the cotangent `cur` at the output of the interval's last factor: exponential boundary for dL/dtau
+            if (st.sta == 0) {
                 int rc = on_stage_end(it.stage, cur, xs[M]);
                 if (rc) return rc;
             }
         }
         int rc = launch_chain(rt, ws, cs, stream);
         if (rc) return rc;
-        if (cs.has_p) {
-            cur = cs.v_out;
-            if (cs.has_q && items[M - j].stage != items[M - 1 - j].stage) {
-                rc = on_stage_end(items[M - 1 - j].stage, cur, xs[M - j]);
+        if (cs.has_p && st.completes) {
+            cur = cs.v_out;  // complete cotangent at the INPUT of forward factor f = output of forward factor f-1
+            const int f = M - 1 - st.fin;
+            if (f >= 1 && items[f].stage != items[f - 1].stage) {
+                rc = on_stage_end(items[f - 1].stage, cur, xs[f]);
                 if (rc) return rc;
             }
         }
@@ -1349,7 +1411,10 @@ int rydiff_set_kernel_variant(int variant) {
     // 0 auto | 1 direct | 2 chained tiles, 512 threads | 3 chained tiles, 256 threads | 4 chained tiles, 1024 threads
     // 5 single-pass LDS tiles with partner-tile loads (forward / recompute passes; adjoint stays direct)
     // 6 chained tiles with sub-tile pipelining (13 <= N <= 22; experimental)
-    if (variant < 0 || variant > 6) return fail(RYDIFF_EINVAL, "kernel variant must be 0..6");
+    // 7 auto, but three tile layouts wherever they are legal (21 <= N <= 28; default from N = 23)
+    if (variant < 0 || variant > 7) return fail(RYDIFF_EINVAL, "kernel variant must be 0..7");
+    g_force_three_layouts = variant == 7;
+    if (variant == 7) variant = 0;
     g_kernel_variant = variant;
     g_chain_lgt = variant == 3 ? 8 : (variant == 4 ? 10 : 9);
     return RYDIFF_OK;
@@ -1384,7 +1449,7 @@ int rydiff_plan(const RydProblem* p, int need_tape, int need_backward, void* scr
     rc = finish_runtime(rt, lo, hi);
     if (rc) return rc;
     int tm = need_tape;
-    if (tm == 2 && !(rt.pl.N > kTileBitsHost && rt.pl.N <= 2 * kTileBitsHost && g_kernel_variant != 1 && g_kernel_variant != 5)) tm = 1;
+    if (tm == 2 && !(rt.pl.N > kTileBitsHost && rt.pl.N <= 28 && g_kernel_variant != 1 && g_kernel_variant != 5)) tm = 1;
     const size_t ws = carve(rt.pl, tm, need_backward != 0, std::max(rt.max_step_factors - 1, 1), rt.total_factors);
     fill_info(rt, lo, hi, ws, info);
     return RYDIFF_OK;
