@@ -145,6 +145,16 @@ __device__ __forceinline__ void partner_sums(const double2* __restrict__ tile, c
     }
 }
 
+#ifdef RYDIFF_TIMELINE
+__device__ unsigned long long g_timeline[4096 * 8];  // tuning builds: per-workgroup phase timestamps of the last launch
+#define RYDIFF_TL(slot)                                                                                   \
+    do {                                                                                                  \
+        if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096 && a.has_p && a.has_q) g_timeline[blockIdx.x * 8 + (slot)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define RYDIFF_TL(slot)
+#endif
+
 template <int LT, int LGT, bool CPLX, bool BWD>
 __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     constexpr int NT = 1 << LGT, R = 1 << (LT - LGT);
@@ -164,6 +174,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     // de-synchronise the workgroups' load / store phases (all tiles are co-resident and start together)
     for (unsigned sl = 0; sl < (blockIdx.x % RYDIFF_STAGGER_PHASES); ++sl) __builtin_amdgcn_s_sleep(RYDIFF_STAGGER);
 #endif
+    RYDIFF_TL(0);
     double2 uu[R], acc[R];
     unsigned xg[R];
 #pragma unroll
@@ -191,6 +202,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     for (int r = 0; r < R; ++r) tile[unsigned(r) * NT + tid] = uu[r];
     __syncthreads();
 #endif
+    RYDIFF_TL(1);
     double* ge_fin = nullptr;
     double* ge_sta = nullptr;
     if (BWD) {
@@ -249,10 +261,12 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
 #pragma unroll
         for (int r = 0; r < R; ++r) xs[r] = stream_load(a.x_sta + boff + xg[r]);
     }
+    RYDIFF_TL(2);
     if (a.write_v) {
 #pragma unroll
         for (int r = 0; r < R; ++r) stream_store(a.v_out + boff + xg[r], acc[r]);
     }
+    RYDIFF_TL(3);
     if (!BWD && a.obs) {  // <v|O|v> for diagonal observables, straight from the registers that hold v
         for (int o = 0; o < a.n_obs; ++o) {
             double e = 0.0;
@@ -269,6 +283,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     for (int r = 0; r < R; ++r) tile[unsigned(r) * NT + tid] = acc[r];
     __syncthreads();
 #endif
+    RYDIFF_TL(4);
 
     const double* __restrict__ cf = a.coef_sta + blockIdx.y * a.coef_bstride;
     // interaction diagonal: remote part of this tile + cross terms of the tile bits that are in |r> (n = 1 - bit)
@@ -369,6 +384,12 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
             wg_atomic_add<NT>(a.cb_sta_r * z2i + a.cb_sta_i * z2r, ge_sta + a.ga + g, red);
         }
     }
+    RYDIFF_TL(5);
 #pragma unroll
     for (int r = 0; r < R; ++r) stream_store(a.q_out + boff + xg[r], q[r]);
+    RYDIFF_TL(6);
+#ifdef RYDIFF_TIMELINE
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): the stores of this wave have been acknowledged
+    RYDIFF_TL(7);
+#endif
 }

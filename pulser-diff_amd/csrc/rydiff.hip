@@ -1407,6 +1407,12 @@ extern "C" {
 const char* rydiff_last_error(void) { return g_last_error.c_str(); }
 const char* rydiff_version(void) { return "rydiff 0.1 (gfx950)"; }
 
+#ifdef RYDIFF_TIMELINE
+int rydiff_debug_timeline(unsigned long long* host_buf, int n_entries) {  // tuning builds only
+    return hipMemcpyFromSymbol(host_buf, HIP_SYMBOL(g_timeline), size_t(n_entries) * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+}
+#endif
+
 int rydiff_set_kernel_variant(int variant) {
     // 0 auto | 1 direct | 2 chained tiles, 512 threads | 3 chained tiles, 256 threads | 4 chained tiles, 1024 threads
     // 5 single-pass LDS tiles with partner-tile loads (forward / recompute passes; adjoint stays direct)
