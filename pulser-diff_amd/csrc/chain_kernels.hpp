@@ -98,6 +98,30 @@ __device__ __forceinline__ void wg_atomic_add(double v, double* dst, double* red
     }
 }
 
+// Deferred gradient reductions of the adjoint pass: every per-thread contribution is reduced over its wave right away and
+// parked per wave in an LDS slot (no barrier); ONE barrier at the end of the kernel, then thread s sums slot s over the
+// waves and issues the atomic.  (A workgroup reduction per value costs two barriers and ~1.8 k cycles; the adjoint pass has
+// five of them for one amplitude and one detuning group: 9 k of its 52 k cycles.)
+template <int NW>
+__device__ __forceinline__ void park2(double v0, double v1, double* red, int slot0, int slot1) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {  // two independent shuffle chains interleave
+        v0 += __shfl_down(v0, off, 64);
+        v1 += __shfl_down(v1, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[slot0 * NW + (threadIdx.x >> 6)] = v0;
+        red[slot1 * NW + (threadIdx.x >> 6)] = v1;
+    }
+}
+
+template <int NW>
+__device__ __forceinline__ void park1(double v0, double* red, int slot0) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v0 += __shfl_down(v0, off, 64);
+    if ((threadIdx.x & 63) == 0) red[slot0 * NW + (threadIdx.x >> 6)] = v0;
+}
+
 // partner sums over the tile bits in `mask`:  ts[r] = sum of partners, ds[r] = sum(+partner if own bit set else -partner)
 template <int LT, int LGT, bool CPLX>
 __device__ __forceinline__ void partner_sums(const double2* __restrict__ tile, const double2 (&reg)[1 << (LT - LGT)],
@@ -159,7 +183,26 @@ template <int LT, int LGT, bool CPLX, bool BWD>
 __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     constexpr int NT = 1 << LGT, R = 1 << (LT - LGT);
     extern __shared__ __attribute__((aligned(16))) double2 tile[];
-    double* red = reinterpret_cast<double*>(tile + (size_t(1) << LT));  // NT/64 doubles behind the tile (BWD only)
+    // behind the tile: NT/64 doubles (forward: fused expectation) or [4 ga + gd][NT/64] parked gradient partials (adjoint)
+    double* red = reinterpret_cast<double*>(tile + (size_t(1) << LT));
+    constexpr int NW = NT / 64;
+    const int n_slots = BWD ? 4 * a.ga + a.gd : 0;  // fin: (re, im) per group | sta: det per group | sta: (re, im) per group
+    if (BWD) {
+        for (int s = int(threadIdx.x); s < n_slots * NW; s += NT) red[s] = 0.0;  // published by the barrier after the tile write
+    }
+    auto flush_gradients = [&](double* ge_fin_, double* ge_sta_) {
+        __syncthreads();
+        for (int s = int(threadIdx.x); s < n_slots; s += NT) {
+            double sum = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sum += red[s * NW + w];
+            double* dst;
+            if (s < 2 * a.ga) dst = ge_fin_ + ((s & 1) ? a.ga : 0) + (s >> 1);
+            else if (s < 2 * a.ga + a.gd) dst = ge_sta_ + 2 * a.ga + (s - 2 * a.ga);
+            else dst = ge_sta_ + (((s - 2 * a.ga - a.gd) & 1) ? a.ga : 0) + ((s - 2 * a.ga - a.gd) >> 1);
+            if (sum != 0.0) unsafeAtomicAdd(dst, sum);
+        }
+    };
     const unsigned tid = threadIdx.x;
     // XCD-aware tile order (speed only): workgroups b and b+8 share an XCD's L2, so give each XCD a contiguous block of
     // tiles — the partner tiles of the low tile-index bits are then hits in that L2
@@ -249,8 +292,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
                     z2r += ds[r].x * xf[r].x + ds[r].y * xf[r].y;
                     z2i += ds[r].x * xf[r].y - ds[r].y * xf[r].x;
                 }
-                wg_atomic_add<NT>(a.cb_fin_r * z1r - a.cb_fin_i * z1i, ge_fin + g, red);
-                wg_atomic_add<NT>(a.cb_fin_r * z2i + a.cb_fin_i * z2r, ge_fin + a.ga + g, red);
+                park2<NW>(a.cb_fin_r * z1r - a.cb_fin_i * z1i, a.cb_fin_r * z2i + a.cb_fin_i * z2r, red, 2 * g, 2 * g + 1);
             }
         }
     } else {
@@ -275,7 +317,10 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
             wg_atomic_add<NT>(e, a.expect_slot + o * a.exp_ostride + blockIdx.y, red);
         }
     }
-    if (!a.has_q) return;
+    if (!a.has_q) {
+        if (BWD) flush_gradients(ge_fin, ge_sta);
+        return;
+    }
 
 #ifndef RYDIFF_ABLATE_SYNC
     __syncthreads();  // all partner reads of u are done
@@ -313,7 +358,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
             double sgd = 0.0;
 #pragma unroll
             for (int r = 0; r < R; ++r) sgd += rr[r] * double(a.dcnt[g] - __popc(xg[r] & a.dmask[g]));
-            wg_atomic_add<NT>(sgd, ge_sta + 2 * a.ga + g, red);
+            park1<NW>(sgd, red, 2 * a.ga + g);
         }
     }
     double2 q[R];
@@ -380,13 +425,14 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
                 z2r += ds[r].x * xs[r].x + ds[r].y * xs[r].y;
                 z2i += ds[r].x * xs[r].y - ds[r].y * xs[r].x;
             }
-            wg_atomic_add<NT>(a.cb_sta_r * z1r - a.cb_sta_i * z1i, ge_sta + g, red);
-            wg_atomic_add<NT>(a.cb_sta_r * z2i + a.cb_sta_i * z2r, ge_sta + a.ga + g, red);
+            park2<NW>(a.cb_sta_r * z1r - a.cb_sta_i * z1i, a.cb_sta_r * z2i + a.cb_sta_i * z2r, red, 2 * a.ga + a.gd + 2 * g,
+                      2 * a.ga + a.gd + 2 * g + 1);
         }
     }
     RYDIFF_TL(5);
 #pragma unroll
     for (int r = 0; r < R; ++r) stream_store(a.q_out + boff + xg[r], q[r]);
+    if (BWD) flush_gradients(ge_fin, ge_sta);
     RYDIFF_TL(6);
 #ifdef RYDIFF_TIMELINE
     __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): the stores of this wave have been acknowledged

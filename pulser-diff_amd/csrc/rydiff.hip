@@ -976,10 +976,13 @@ struct ChainStep {
 template <int LGT, bool CPLX, bool BWD>
 int launch_chain_t(const ChainArgs& ca, unsigned tiles, int B, hipStream_t stream) {
     static bool attr_set = false;
-    const size_t lds = (size_t(1) << kTileBits) * sizeof(double2) + 256;
+    // tile + reduction scratch: one double per wave (forward), [4 ga + gd] slots per wave (adjoint: parked gradient partials)
+    const size_t nw = (size_t(1) << LGT) / 64;
+    const size_t max_lds = (size_t(1) << kTileBits) * sizeof(double2) + 256 + (BWD ? size_t(5) * kMaxGroups * nw * sizeof(double) : 0);
+    const size_t lds = (size_t(1) << kTileBits) * sizeof(double2) + 256 + (BWD ? size_t(4 * ca.ga + ca.gd) * nw * sizeof(double) : 0);
     auto kern = k_chain<kTileBits, LGT, CPLX, BWD>;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(max_lds)));
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(tiles, B), dim3(1 << LGT), lds, stream, ca);
