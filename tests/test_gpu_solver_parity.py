@@ -243,7 +243,7 @@ def _run_variant(variant, terms, tsave, psi_bd, device, obs, grads=True, batch_t
 @pytest.mark.parametrize("n_qubits,local,variant", [(13, True, 2), (14, False, 3), (16, True, 4), (17, True, 2), (20, False, 2),
                                                      (13, True, 5), (18, True, 5), (20, False, 5),
                                                      (13, True, 6), (16, False, 6), (17, True, 6), (20, True, 6), (22, False, 6),
-                                                     (21, True, 7), (22, True, 7), (23, True, 0), (24, False, 0)])
+                                                     (21, True, 7), (22, True, 7), (23, True, 0), (24, False, 0), (25, True, 0)])
 def test_chained_tile_kernels_match_direct_kernels(cuda_device, n_qubits, local, variant):
     """A/B on the GPU: the chained LDS-tile kernels (two tile layouts up to 22 qubits, three from 23 — variant 7 forces
     three wherever legal) against the one-amplitude-per-thread kernels (which are themselves pinned to the oracle
