@@ -51,6 +51,7 @@ extern "C" {
 #endif
 
 #define RYDIFF_MAX_QUBITS 30
+#define RYDIFF_MAX_PAIR_TERMS 15
 #define RYDIFF_MAX_TERMS 64
 
 enum { RYDIFF_OK = 0, RYDIFF_EINVAL = -1, RYDIFF_EWORKSPACE = -2, RYDIFF_EHIP = -3, RYDIFF_ENOTIMPL = -4 };
@@ -81,6 +82,16 @@ typedef struct RydProblem {
 
     int32_t n_obs;         /* diagonal observables evaluated at every tsave (utils.py:79-81 for diagonal O) */
     const double* obs_diag;/* DEVICE float64 [n_obs][2^N] */
+
+    /* Optional dense two-qubit terms of the generator M in d/dt v = -i M(t) v — how the master-equation path
+     * (backend.py:495-509, SolverType.DP5_ME) runs on this library: rho is the state of a DOUBLED register (row qubits,
+     * column qubits), the commutator is an ordinary structured "Hamiltonian" on it, and every collapse operator acting
+     * on qubit j contributes a constant 4x4 block on the pair (row qubit j, column qubit j):
+     *   (M v)[x] += sum_{s=0..3} T_p[4*own + s] * v[x with the bits of qubits (a_p, b_p) set to s],
+     * own / s = 2*bit(a_p) + bit(b_p).  M need not be Hermitian.  Problems with pair terms run on the direct kernels. */
+    int32_t n_pair_terms;          /* 0..RYDIFF_MAX_PAIR_TERMS */
+    const uint32_t* pair_qubits;   /* HOST [n_pair_terms][2]: (a_p, b_p), a_p != b_p */
+    const double* pair_tables;     /* HOST complex128 as (re, im) [n_pair_terms][16] */
 } RydProblem;
 
 /* Result of rydiff_plan(): everything that depends on the VALUES in the coefficient tables. */

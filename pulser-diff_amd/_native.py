@@ -47,6 +47,9 @@ class RydProblem(ctypes.Structure):
         ("tol", ctypes.c_double),
         ("n_obs", ctypes.c_int32),
         ("obs_diag", ctypes.c_void_p),
+        ("n_pair_terms", ctypes.c_int32),
+        ("pair_qubits", ctypes.c_void_p),
+        ("pair_tables", ctypes.c_void_p),
     ]
 
 

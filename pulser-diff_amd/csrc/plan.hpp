@@ -52,6 +52,12 @@ struct Plan {
     std::vector<Stage> stages;
     std::vector<int> step_begin;  // stages of step k are [step_begin[k], step_begin[k+1])
     std::vector<double> tsave;
+    // dense two-qubit terms (master equation on the doubled register): index-bit masks, tables [p][fwd | adjoint][16] (re, im)
+    int n_pair = 0;
+    uint32_t pair_ma[RYDIFF_MAX_PAIR_TERMS] = {0}, pair_mb[RYDIFF_MAX_PAIR_TERMS] = {0};
+    std::vector<double> pair_tab;
+    double pair_radius = 0.0;  // Gershgorin radius of the pair terms (sum over terms of the largest absolute row sum)
+    size_t off_pair = 0;
 
     // workspace offsets (bytes)
     size_t off_meta_idx = 0, off_meta_w = 0, off_coef = 0, off_stats = 0, off_udiag = 0, off_buf0 = 0, off_buf1 = 0;
@@ -136,6 +142,39 @@ inline bool build_plan(const RydProblem* p, Plan& pl, std::string& err) {
     if (p->solver != RYDIFF_SOLVER_KRYLOV_SE && p->solver != RYDIFF_SOLVER_DP5_SE) {
         err = "unknown solver";
         return false;
+    }
+    if (p->n_pair_terms < 0 || p->n_pair_terms > RYDIFF_MAX_PAIR_TERMS || (p->n_pair_terms > 0 && (!p->pair_qubits || !p->pair_tables))) {
+        err = "bad pair terms";
+        return false;
+    }
+    pl.n_pair = p->n_pair_terms;
+    pl.pair_tab.assign(size_t(pl.n_pair) * 64, 0.0);
+    pl.pair_radius = 0.0;
+    for (int t = 0; t < pl.n_pair; ++t) {
+        const uint32_t qa = p->pair_qubits[2 * t], qb = p->pair_qubits[2 * t + 1];
+        if (qa >= uint32_t(p->n_qubits) || qb >= uint32_t(p->n_qubits) || qa == qb) {
+            err = "pair term addresses qubits outside the register";
+            return false;
+        }
+        pl.pair_ma[t] = 1u << (p->n_qubits - 1 - qa);
+        pl.pair_mb[t] = 1u << (p->n_qubits - 1 - qb);
+        const double* src = p->pair_tables + size_t(t) * 32;
+        double* fwd = pl.pair_tab.data() + size_t(t) * 64;
+        double* adj = fwd + 32;
+        double worst = 0.0;
+        for (int r = 0; r < 4; ++r) {
+            double row = 0.0;
+            for (int c = 0; c < 4; ++c) {
+                const double re = src[2 * (4 * r + c)], im = src[2 * (4 * r + c) + 1];
+                fwd[2 * (4 * r + c)] = re;
+                fwd[2 * (4 * r + c) + 1] = im;
+                adj[2 * (4 * c + r)] = re;  // conjugate transpose
+                adj[2 * (4 * c + r) + 1] = -im;
+                row += std::sqrt(re * re + im * im);
+            }
+            worst = std::max(worst, row);
+        }
+        pl.pair_radius += worst;
     }
     pl.N = p->n_qubits;
     pl.dim = size_t(1) << pl.N;
@@ -285,6 +324,7 @@ inline size_t carve(Plan& pl, int tape_mode, bool need_backward, int chain_slots
     // split interaction diagonal for the two tile layouts: utt[2][4096] + vr[2][tiles][16]
     pl.off_split = take(3 * (4096 + (pl.dim >> 12 ? (pl.dim >> 12) : 1) * 16) * sizeof(double));  // up to three tile layouts
     pl.off_ptable = take(pl.ptable_bytes);
+    pl.off_pair = take(size_t(pl.n_pair) * 64 * sizeof(double));
     pl.total_fwd = off;
     pl.tape_mode = tape_mode;
     if (tape_mode == 2) pl.off_tape = take(size_t(total_factors + 1) * pl.state_bytes);

@@ -67,6 +67,34 @@ struct GroupArgs {
     int dcnt[kMaxGroups];        // qubits per detuning group
 };
 
+// dense two-qubit terms of the generator (include/rydiff.h: pair terms)
+struct PairArgs {
+    int n = 0;
+    const double2* tab = nullptr;  // [n][2][16]: forward table, then its conjugate transpose
+    uint32_t ma[RYDIFF_MAX_PAIR_TERMS];
+    uint32_t mb[RYDIFF_MAX_PAIR_TERMS];
+};
+
+// sum_p sum_s T_p[4*own + s] * v[x with the pair's bits set to s];  which = 0: T, 1: T^dagger
+__device__ __forceinline__ double2 pair_apply(const PairArgs& pa, int which, const double2* __restrict__ v, uint32_t x) {
+    double2 acc = make_double2(0.0, 0.0);
+    for (int t = 0; t < pa.n; ++t) {
+        const uint32_t ma = pa.ma[t], mb = pa.mb[t];
+        const int own = ((x & ma) ? 2 : 0) | ((x & mb) ? 1 : 0);
+        const uint32_t base = x & ~(ma | mb);
+        const double2* __restrict__ row = pa.tab + (size_t(t) * 2 + which) * 16 + own * 4;
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const double2 c = row[sidx];
+            if (c.x == 0.0 && c.y == 0.0) continue;
+            const double2 q = v[base | ((sidx & 2) ? ma : 0u) | ((sidx & 1) ? mb : 0u)];
+            acc.x += c.x * q.x - c.y * q.y;
+            acc.y += c.x * q.y + c.y * q.x;
+        }
+    }
+    return acc;
+}
+
 struct FactorArgs {
     const double2* xin;
     double2* xout;
@@ -83,6 +111,7 @@ struct FactorArgs {
     int n_remote;
     const double2* remote[kMaxRemote];
     double rc[2 * kMaxRemote];
+    PairArgs pair;
 };
 
 struct FactorBwdArgs {
@@ -99,6 +128,7 @@ struct FactorBwdArgs {
     uint32_t dim;
     double gr, gi, br, bi;
     GroupArgs g;
+    PairArgs pair;
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -357,6 +387,11 @@ __global__ __launch_bounds__(256) void k_factor_direct(FactorArgs a) {
         ar += b1r * s1r - b1i * s1i + b0r * s0r - b0i * s0i;
         ai += b1r * s1i + b1i * s1r + b0r * s0i + b0i * s0r;
     }
+    if (a.pair.n) {  // beta * (dense two-qubit terms)
+        const double2 pv = pair_apply(a.pair, 0, xin, x);
+        ar += a.br * pv.x - a.bi * pv.y;
+        ai += a.br * pv.y + a.bi * pv.x;
+    }
     a.xout[boff + x] = make_double2(ar, ai);
 }
 
@@ -426,6 +461,11 @@ __global__ __launch_bounds__(256) void k_factor_bwd_direct(FactorBwdArgs a) {
         const double v = live ? r * double(a.g.dcnt[q] - __popc(x & a.g.dmask[q])) : 0.0;
         block_atomic_add(v, ge + 2 * a.g.ga + q, lds);
     }
+    if (a.pair.n && live) {  // conj(beta) * (pair terms)^dagger applied to the cotangent
+        const double2 pv = pair_apply(a.pair, 1, gin, x);
+        ar += a.br * pv.x + a.bi * pv.y;
+        ai += a.br * pv.y - a.bi * pv.x;
+    }
     if (live) a.gout[boff + x] = make_double2(ar, ai);
 }
 
@@ -441,6 +481,7 @@ struct DotHArgs {
     long out_rstride;
     uint32_t dim;
     GroupArgs gr;
+    PairArgs pair;
 };
 
 __global__ __launch_bounds__(256) void k_dot_hx(DotHArgs a) {
@@ -466,6 +507,11 @@ __global__ __launch_bounds__(256) void k_dot_hx(DotHArgs a) {
         const double cr = cf[q], ci = cf[a.gr.ga + q];
         hr += cr * s1r - ci * s1i + cr * s0r + ci * s0i;
         hi += cr * s1i + ci * s1r + cr * s0i - ci * s0r;
+    }
+    if (a.pair.n) {
+        const double2 pv = pair_apply(a.pair, 0, xin, xs);
+        hr += pv.x;
+        hi += pv.y;
     }
     const double2 g = (a.g + boff)[xs];
     // Im(conj(g) * h) = g.x*hi - g.y*hr
@@ -660,6 +706,7 @@ struct Runtime {
     int max_step_factors = 0;
     int flags = 0;
     GroupArgs garg{};
+    PairArgs parg{};
 };
 
 std::mutex g_poly_mutex;
@@ -689,6 +736,8 @@ void fill_group_args(const Plan& pl, GroupArgs& g) {
 int finish_runtime(Runtime& rt, double lo, double hi) {
     Plan& pl = rt.pl;
     if (!(hi >= lo) || !std::isfinite(hi) || !std::isfinite(lo)) return fail(RYDIFF_EINVAL, "non-finite spectral bounds (NaN/Inf in the coefficient tables?)");
+    lo -= pl.pair_radius;  // dense two-qubit (dissipator) terms: keep the whole numerical range inside the design interval
+    hi += pl.pair_radius;
     rt.sigma = 0.5 * (hi + lo);
     rt.width = std::max(0.5 * (hi - lo), 1e-9);
     double rho_d = 1e-6;
@@ -711,6 +760,11 @@ int finish_runtime(Runtime& rt, double lo, double hi) {
         rt.max_step_factors = std::max(rt.max_step_factors, f);
     }
     fill_group_args(pl, rt.garg);
+    rt.parg.n = pl.n_pair;
+    for (int t = 0; t < pl.n_pair; ++t) {
+        rt.parg.ma[t] = pl.pair_ma[t];
+        rt.parg.mb[t] = pl.pair_mb[t];
+    }
     return RYDIFF_OK;
 }
 
@@ -767,6 +821,11 @@ void fill_info(const Runtime& rt, double lo, double hi, size_t ws, RydPlanInfo* 
     info->workspace_bytes = ws;
 }
 
+// the full per-factor tape exists only where the chained tile passes run
+bool full_tape_possible(const Plan& pl) {
+    return pl.N > kTileBitsHost && pl.N <= 28 && pl.n_pair == 0 && g_kernel_variant != 1 && g_kernel_variant != 5;
+}
+
 // common prologue of forward / backward: plan, (optional) stats, carve, upload metadata, expand coefficients, udiag
 int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_t workspace_bytes, int need_tape,
             bool need_backward, hipStream_t stream, Runtime& rt) {
@@ -786,7 +845,7 @@ int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_
     int rc = finish_runtime(rt, lo, hi);
     if (rc) return rc;
     Plan& pl = rt.pl;
-    if (need_tape == 2 && !(pl.N > kTileBitsHost && pl.N <= 2 * kTileBitsHost && g_kernel_variant != 1 && g_kernel_variant != 5)) need_tape = 1;  // full tape only with chained passes
+    if (need_tape == 2 && !full_tape_possible(pl)) need_tape = 1;  // full tape only with chained passes
     const size_t need = carve(pl, need_tape, need_backward, std::max(rt.max_step_factors - 1, 1), rt.total_factors);
     if (workspace_bytes < need)
         return fail(RYDIFF_EWORKSPACE, "workspace too small: need " + std::to_string(need) + " bytes, got " + std::to_string(workspace_bytes));
@@ -802,6 +861,10 @@ int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_
         }
     HIP_TRY(hipMemcpyAsync(ws + pl.off_meta_idx, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(ws + pl.off_meta_w, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    if (pl.n_pair) {
+        HIP_TRY(hipMemcpyAsync(ws + pl.off_pair, pl.pair_tab.data(), pl.pair_tab.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+        rt.parg.tab = reinterpret_cast<const double2*>(ws + pl.off_pair);
+    }
     HIP_TRY(hipStreamSynchronize(stream));  // idx/w are stack vectors: make sure the copies are done before they die
     if (pl.NC > 0) {
         ExpandArgs ea{};
@@ -900,6 +963,7 @@ int launch_factor(const Runtime& rt, char* ws, const double2* xin, double2* xout
     fa.br = s.br;
     fa.bi = s.bi;
     fa.g = rt.garg;
+    fa.pair = rt.parg;
     dim3 grid(unsigned((pl.dim + 255) / 256), pl.B);
     hipLaunchKernelGGL(k_factor_direct, grid, dim3(256), 0, stream, fa);
     LAUNCH_CHECK();
@@ -944,7 +1008,7 @@ uint32_t to_tile_mask(const LayoutDesc& d, uint32_t index_mask) {
 
 bool chain_enabled(const Runtime& rt) {
     const int N = rt.pl.N;
-    if (g_kernel_variant == 1 || g_kernel_variant == 5) return false;
+    if (g_kernel_variant == 1 || g_kernel_variant == 5 || rt.pl.n_pair) return false;  // pair terms: direct kernels
     return N > kTileBits && N <= 28;
 }
 
@@ -1229,7 +1293,7 @@ int run_chain(const Runtime& rt, char* ws, const std::vector<ChainItem>& items, 
 
 bool single_pass_enabled(const Runtime& rt) {
     const int N = rt.pl.N;
-    if (g_kernel_variant == 5) return N > kTileBits && N <= 24;
+    if (g_kernel_variant == 5) return N > kTileBits && N <= 24 && rt.pl.n_pair == 0;
     return false;
 }
 
@@ -1329,7 +1393,7 @@ int run_chain_bwd(const Runtime& rt, char* ws, const std::vector<ChainItem>& ite
 }
 
 // ---- persistent small-N forward (k_persist) ------------------------------------------------------------------------
-bool persist_enabled(const Runtime& rt) { return g_kernel_variant != 1 && rt.pl.N <= kTileBits; }
+bool persist_enabled(const Runtime& rt) { return g_kernel_variant != 1 && rt.pl.N <= kTileBits && rt.pl.n_pair == 0; }
 
 template <int LT, bool CPLX>
 int launch_persist_t(const PersistArgs& pa, int B, hipStream_t stream) {
@@ -1458,7 +1522,7 @@ int rydiff_plan(const RydProblem* p, int need_tape, int need_backward, void* scr
     rc = finish_runtime(rt, lo, hi);
     if (rc) return rc;
     int tm = need_tape;
-    if (tm == 2 && !(rt.pl.N > kTileBitsHost && rt.pl.N <= 28 && g_kernel_variant != 1 && g_kernel_variant != 5)) tm = 1;
+    if (tm == 2 && !full_tape_possible(rt.pl)) tm = 1;
     const size_t ws = carve(rt.pl, tm, need_backward != 0, std::max(rt.max_step_factors - 1, 1), rt.total_factors);
     fill_info(rt, lo, hi, ws, info);
     return RYDIFF_OK;
@@ -1735,6 +1799,7 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
             da.out_rstride = pl.NC + 1;
             da.dim = uint32_t(pl.dim);
             da.gr = rt.garg;
+            da.pair = rt.parg;
             hipLaunchKernelGGL(k_dot_hx, grid, dim3(256), 0, stream, da);
             LAUNCH_CHECK();
             return RYDIFF_OK;
@@ -1759,6 +1824,7 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
                 da.out_rstride = pl.NC + 1;
                 da.dim = uint32_t(pl.dim);
                 da.gr = rt.garg;
+            da.pair = rt.parg;
                 hipLaunchKernelGGL(k_dot_hx, grid, dim3(256), 0, stream, da);
                 LAUNCH_CHECK();
             }
@@ -1779,6 +1845,7 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
             ba.br = it.s.br;
             ba.bi = it.s.bi;
             ba.g = rt.garg;
+            ba.pair = rt.parg;
             hipLaunchKernelGGL(k_factor_bwd_direct, grid, dim3(256), 0, stream, ba);
             LAUNCH_CHECK();
             cl ^= 1;
@@ -1870,6 +1937,7 @@ int rydiff_apply_factor(const RydProblem* p, const double* c_amp_reim, const dou
     std::string err;
     if (!build_plan(&q, rt.pl, err)) return fail(RYDIFF_EINVAL, err);
     Plan& pl = rt.pl;
+    if (pl.n_pair) return fail(RYDIFF_ENOTIMPL, "rydiff_apply_factor does not take pair terms");
     fill_group_args(pl, rt.garg);
     const size_t need = align_up(pl.dim * sizeof(double));
     if (workspace_bytes < need) return fail(RYDIFF_EWORKSPACE, "workspace too small: need " + std::to_string(need));

@@ -51,6 +51,8 @@ class ProblemSpec:
     store_states: bool = True
     tape: str = "auto"  # with store_states=False and gradients: "steps" | "full" | "auto" (full when it fits in HBM)
     options: dict = field(default_factory=dict)
+    # dense two-qubit terms of the generator (include/rydiff.h): ((qubit_a, qubit_b, 4x4 complex table), ...); constants
+    pair_terms: tuple = ()
 
     def solver_code(self) -> int:
         if self.solver not in _SOLVER_CODE:
@@ -114,6 +116,12 @@ class _Call:
         p.tol = spec.tol
         p.n_obs = 0 if obs is None else obs.shape[0]
         p.obs_diag = None if obs is None or obs.shape[0] == 0 else obs.data_ptr()
+        self.pair_qubits = np.ascontiguousarray([[a, b] for a, b, _ in spec.pair_terms], dtype=np.uint32).reshape(-1, 2)
+        self.pair_tables = np.ascontiguousarray([np.asarray(t, dtype=np.complex128).reshape(16) for _, _, t in spec.pair_terms],
+                                                dtype=np.complex128).reshape(-1, 16)
+        p.n_pair_terms = len(spec.pair_terms)
+        p.pair_qubits = self.pair_qubits.ctypes.data if spec.pair_terms else None
+        p.pair_tables = self.pair_tables.ctypes.data if spec.pair_terms else None
         self.problem = p
 
 
