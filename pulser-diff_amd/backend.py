@@ -8,8 +8,9 @@ What changes for a user switching over:
     and keeps the trajectory inside the solver workspace — the only way to run a 20-qubit sequence, where a dense
     observable (2^40 entries) or an autograd tape through every sub-step cannot exist;
   * stochastic noise (``SimConfig(noise=("doppler", "amplitude", "SPAM"))``) runs all realisations as ONE batch of
-    trajectories and returns ``NoisyResults``; noise that needs collapse operators, the digital / XY bases and SLM masks
-    raise ``NotImplementedError``.
+    trajectories and returns ``NoisyResults``; collapse-operator noise (dephasing, relaxation, depolarizing, eff_noise) and
+    ``SolverType.DP5_ME`` run the master equation on a doubled register (``lindblad.py``) and return density matrices;
+    the digital / XY bases, leakage and SLM masks raise ``NotImplementedError``.
 """
 from __future__ import annotations
 
@@ -23,7 +24,8 @@ import torch
 from torch import Tensor
 
 from . import pulser_adapter, pulses
-from .hamiltonian import Hamiltonian
+from .hamiltonian import COLLAPSE_NOISES, Hamiltonian
+from .lindblad import mesolve
 from .result import SampledResult
 from .simconfig import SimConfig
 from .simresults import CoherentResults, NoisyResults, SimulationResults
@@ -269,9 +271,9 @@ class TorchEmulator:
                     v.requires_grad_(True)  # constant register: make r_ij a leaf and reconnect U_ij to it
                 self.dist_dict[k] = v
             self._hamiltonian._rebuild_u_pairs()
-        if solver == SolverType.DP5_ME:
-            raise NotImplementedError("The master-equation solver DP5_ME is not part of the native hot path.")
-        if solver not in (SolverType.DP5_SE, SolverType.KRYLOV_SE):
+        if set(self.config.noise) & COLLAPSE_NOISES:  # backend.py:482-488: collapse operators force the master equation
+            solver = SolverType.DP5_ME
+        if solver not in (SolverType.DP5_SE, SolverType.KRYLOV_SE, SolverType.DP5_ME):
             raise ValueError(f"Solver {solver} not available.")
 
         dev = self._compute_device
@@ -307,6 +309,10 @@ class TorchEmulator:
                                           "state different from the ground.")
 
         def run_coherent() -> CoherentResults:
+            if solver == SolverType.DP5_ME:  # density matrices (backend.py:495-509); without collapse noise L = 0
+                rho, stats = mesolve(ham, psi0.to(dev), self._eval_times_array, ham.config, options)
+                return CoherentResults(rho, ham._size, ham.basis_name, self._eval_times_array, self._meas_basis, meas_errors,
+                                       atom_order=tuple(ham._qdict), stats=stats, density=True)
             result = sesolve(ham, psi0.to(dev), self._eval_times_array, solver=solver, options=options, obs_diag=obs_diag,
                              store_states=store_states)
             states_tbd = result.states.permute(0, 2, 1) if result.states.numel() else result.states
@@ -330,6 +336,9 @@ class TorchEmulator:
             reps = [r for _, r in drawn]
         else:
             reps = [1] * self.config.runs
+        if solver == SolverType.DP5_ME:
+            raise NotImplementedError("Stochastic noise realisations (doppler / amplitude fluctuations / preparation errors) "
+                                      "combined with collapse-operator noise are not implemented: run them separately.")
         return self._run_noisy(psi0, solver, options, reps, bad_atom_configs, meas_errors)
 
     def _run_noisy(self, psi0: Tensor, solver: SolverType, options: dict, reps: list, bad_atom_configs,

@@ -15,7 +15,8 @@ and the native library applies H(t) to the state without ever materialising it. 
 Only the ground-rydberg ("ising") basis is on the hot path.  Stochastic noise (doppler, amplitude, SPAM;
 ``hamiltonian.py:170-219,270-286``) is a perturbation of the sampled coefficient arrays, i.e. more trajectories of the same
 Schroedinger problem: ``noisy_batch_tables`` draws all realisations at once and returns per-run tables for ONE batched
-call of the native solver.  Noise types that need collapse operators (Lindblad) raise NotImplementedError.
+call of the native solver.  Noise types with collapse operators (hamiltonian.py:98-143) are kept as single-qubit operators
+and run through the master-equation path on the doubled register (``lindblad.py``).
 """
 from __future__ import annotations
 
@@ -33,7 +34,8 @@ from .utils import basis_state, kron
 
 CD = torch.complex128
 RD = torch.float64
-STOCHASTIC_NOISES = {"doppler", "amplitude", "SPAM"}  # realised as extra trajectories; the rest needs collapse operators
+STOCHASTIC_NOISES = {"doppler", "amplitude", "SPAM"}  # realised as extra trajectories of the Schroedinger solver
+COLLAPSE_NOISES = {"dephasing", "relaxation", "depolarizing", "eff_noise"}  # collapse operators: master equation (lindblad.py)
 # pulser_simulation.simconfig.doppler_sigma (not vendored in the reference; published constants of pulser-simulation):
 # thermal Doppler shift of the effective Rydberg transition wave vector for 87Rb
 _KB, _MASS, _KEFF = 1.38e-23, 1.45e-25, 8.7  # J/K, kg, 1/um
@@ -92,12 +94,9 @@ class Hamiltonian:
                 f"Interaction mode '{self._interaction}' does not support "
                 f"simulation of noise types: {', '.join(not_supported)}."
             )
-        lindblad = set(cfg.noise_types) - STOCHASTIC_NOISES
-        if lindblad:
-            raise NotImplementedError(
-                "The MI355X-native backend accelerates the Schroedinger path; noise types "
-                f"{sorted(lindblad)} need collapse operators (master equation) and are not implemented."
-            )
+        unknown = set(cfg.noise_types) - STOCHASTIC_NOISES - COLLAPSE_NOISES
+        if unknown:
+            raise NotImplementedError(f"Noise types {sorted(unknown)} are not implemented in the MI355X-native backend.")
         if not hasattr(self, "basis_name"):
             self._build_basis_and_op_matrices()
         self._config = cfg

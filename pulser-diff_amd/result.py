@@ -42,7 +42,11 @@ class TorchResult:
 
     def _weights(self) -> Tensor:
         """result.py:70-120 for two-level kets: probabilities in the measurement's bitstring order."""
-        probs = (torch.abs(self.state.detach()[:, 0]) ** 2).flatten().cpu()
+        st = self.state.detach()
+        if st.ndim == 3 or (st.ndim == 2 and st.shape[0] == st.shape[1] and st.shape[1] != 1):  # density matrix (result.py:72-73)
+            probs = torch.abs(torch.diagonal(st[..., 0] if st.ndim == 3 else st)).flatten().cpu()
+        else:
+            probs = (torch.abs(st[:, 0]) ** 2).flatten().cpu()
         if self.matching_meas_basis:
             # state ordered with r first ([rr, rg, gr, gg] -> [11, 10, 01, 00]); invert to [00, 01, 10, 11]
             weights = probs.flip(0) if self.meas_basis == "ground-rydberg" else probs

@@ -3,9 +3,9 @@
 
 The hot path this backend accelerates is the Schroedinger evolution.  Stochastic noise ("doppler", "amplitude",
 "SPAM") perturbs the sampled coefficients / the measurement only, so ``TorchEmulator`` runs its realisations as a batch
-of trajectories; noise types that need collapse operators ("dephasing", "relaxation", "depolarizing", "eff_noise") are
-accepted as value objects (user code that builds configs keeps working) but raise ``NotImplementedError`` when they
-would have to be simulated (the master-equation path is a later row).
+of trajectories; noise types with collapse operators ("dephasing", "relaxation", "depolarizing", "eff_noise") run through
+the master-equation path on the doubled register (``lindblad.py``, ``SolverType.DP5_ME``).  "leakage" (three-level basis)
+raises ``NotImplementedError``.
 """
 from __future__ import annotations
 

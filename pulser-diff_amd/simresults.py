@@ -54,7 +54,7 @@ class CoherentResults(SimulationResults, collections.abc.Sequence):
     def __init__(self, states_tbd: Tensor, size: int, basis_name: str, sim_times: Tensor, meas_basis: str,
                  meas_errors: Optional[Mapping[str, float]] = None, atom_order: tuple = (),
                  native_expect: Optional[Tensor] = None, native_observables: Optional[list] = None,
-                 stats: Optional[dict] = None) -> None:
+                 stats: Optional[dict] = None, density: bool = False) -> None:
         super().__init__(size, basis_name, sim_times)
         if meas_basis != self._basis_name:
             raise ValueError("`meas_basis` and `basis_name` must have the same value.")
@@ -62,6 +62,7 @@ class CoherentResults(SimulationResults, collections.abc.Sequence):
             raise ValueError("Measurement error probabilities must be given in the form `{'epsilon':0.01, 'epsilon_prime':0.05}`")
         self._meas_basis = meas_basis
         self._meas_errors = meas_errors
+        self._density = density  # master-equation run: `states_tbd` holds density matrices (n_t, dim, dim, B) instead
         self._states_tbd = states_tbd  # (n_t, B, dim), possibly empty when states were not stored
         self._atom_order = atom_order
         self._native_expect = native_expect  # (n_obs, n_t, B)
@@ -77,6 +78,8 @@ class CoherentResults(SimulationResults, collections.abc.Sequence):
             return [self[j] for j in range(*i.indices(len(self)))]
         if self._states_tbd.numel() == 0:
             raise RuntimeError("States were not stored for this run (store_states=False).")
+        if self._density:
+            return TorchResult(self._atom_order, self._meas_basis, self._states_tbd[i], True)  # (dim, dim, B)
         return TorchResult(self._atom_order, self._meas_basis, self._states_tbd[i].transpose(0, 1), True)
 
     @property
@@ -84,6 +87,8 @@ class CoherentResults(SimulationResults, collections.abc.Sequence):
         """(n_t, dim, B) like ``torch.stack([res.state for res in self])`` (``simresults.py:398-401``)."""
         if self._states_tbd.numel() == 0:
             raise RuntimeError("States were not stored for this run (store_states=False).")
+        if self._density:
+            return self._states_tbd  # (n_t, dim, dim, B): what mesolve's states stack to (backend.py:513-521)
         return self._states_tbd.permute(0, 2, 1)
 
     def get_state(self, t: float, reduce_to_basis=None, ignore_global_phase: bool = True, tol: float = 1e-6,

@@ -77,9 +77,11 @@ def total_magnetization(n_qubits: int, use_sparse: bool = False) -> Tensor:
 def expect(obs, states: Tensor) -> Tensor:
     """utils.py:68-86.  states: (n_t, dim, B) kets or (n_t, dim, dim, B) density matrices."""
     if isinstance(obs, DiagonalObservable):
-        if states.ndim != 3:
-            raise ValueError("DiagonalObservable expects ket states of shape (n_t, dim, B).")
         d = obs.diag.to(states.device)
+        if states.ndim == 4:  # density matrices: tr(O rho) = sum_x O[x] rho[x, x]
+            return (torch.diagonal(states, dim1=1, dim2=2) * d[None, None, :]).sum(dim=(1, 2)).to(states.dtype)
+        if states.ndim != 3:
+            raise ValueError("DiagonalObservable expects kets (n_t, dim, B) or density matrices (n_t, dim, dim, B).")
         return (states.abs() ** 2 * d[None, :, None]).sum(dim=(1, 2)).to(states.dtype)
     if obs.is_sparse:
         if states.ndim == 3:

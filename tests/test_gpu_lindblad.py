@@ -86,3 +86,48 @@ def test_gradients_through_the_master_equation_match_dense_autograd(cuda_device)
     assert rel_err(ham.det_tables.grad[0].cpu().numpy(), torch.stack([c.grad for c, _ in o.det_terms()]).numpy()) < 1e-7
     assert rel_err(ham.u_pairs.grad.cpu().numpy(), o.u_pairs.grad.numpy()) < 1e-7
     assert rel_err(ts.grad.numpy(), o_ts.grad.numpy()) < 1e-6
+
+
+def test_emulator_runs_the_master_equation_and_returns_density_results(cuda_device):
+    """TorchEmulator.run with collapse-operator noise switches to DP5_ME (backend.py:482-488); results carry density matrices
+    with the reference's shapes (n_t, dim, dim, B), expectation values are tr(O rho), samples come from diag(rho)."""
+    import pulser_diff_amd as P
+    from pulser_diff_amd import pulses as pl
+    from pulser_diff_amd.utils import DiagonalObservable, total_magnetization, total_magnetization_diag
+
+    n = 3
+    seq = pl.Sequence(pl.Register.rectangle(1, n, spacing=8, prefix="q"), pl.MockDevice)
+    seq.declare_channel("g", "rydberg_global")
+    seq.add(pl.Pulse(pl.BlackmanWaveform(300, 2.4), pl.RampWaveform(300, -3.0, 2.0), 0.2), "g")
+    times = [0.05 * k for k in range(1, 7)]
+    clean = P.TorchEmulator.from_sequence(seq, evaluation_times=times).run()
+    cfg = P.SimConfig(noise=("relaxation", "dephasing"), relaxation_rate=0.5, dephasing_rate=1.0)
+    sim = P.TorchEmulator.from_sequence(seq, config=cfg, evaluation_times=times)
+    res = sim.run()  # default solver argument; the noise forces DP5_ME
+    assert res.states.shape == (len(res), 2**n, 2**n, 1)
+    z_dense = res.expect([total_magnetization(n)])[0].real.cpu().numpy()
+    z_diag = res.expect([DiagonalObservable(total_magnetization_diag(n))])[0].real.cpu().numpy()
+    assert np.abs(z_dense - z_diag).max() < 1e-12
+    z_clean = clean.expect([total_magnetization(n)])[0].real.cpu().numpy()
+    assert z_dense[0] == -n and np.abs(z_dense - z_clean).max() > 1e-2  # decoherence changes the dynamics
+    # against the oracle's dense solution of the same sequence
+    ham = sim._hamiltonian
+    terms = R.HamTerms(n, ham._u_pairs_host, ham._amp_terms[0][0], ham._det_terms[0][0], ham.dt, ham.n_samples,
+                       list(range(n)), list(range(n)))
+    psi0 = R.all_ground_state(n)[:, 0]
+    ref = R.lindblad_continuous_solution(terms, R.collapse_operators(n, {"relaxation": 0.5, "dephasing": 1.0}),
+                                         torch.outer(psi0, psi0.conj()).numpy(), sim.evaluation_times.numpy())
+    assert np.abs(res.states[..., 0].cpu().numpy() - ref).max() < 1e-8
+    # purity drops below one, the trace stays one
+    rho_t = res.states[-1, :, :, 0]
+    assert abs(torch.trace(rho_t).real.item() - 1.0) < 1e-9 and torch.trace(rho_t @ rho_t).real.item() < 0.98
+    np.random.seed(0)
+    counts = res.sample_final_state(500)
+    p_ref = np.real(np.diag(ref[-1]))[::-1]
+    assert abs(counts.get("000", 0) / 500 - p_ref[0]) < 5 * np.sqrt(p_ref[0] * (1 - p_ref[0]) / 500)
+    # no noise + explicit DP5_ME: density matrix of the pure-state evolution
+    pure = P.TorchEmulator.from_sequence(seq, evaluation_times=times).run(solver=SolverType.DP5_ME)
+    ket = clean.states[-1, :, 0]
+    assert (pure.states[-1, :, :, 0] - torch.outer(ket, ket.conj())).abs().max().item() < 1e-8
+    with pytest.raises(NotImplementedError, match="combined with collapse-operator noise"):
+        P.TorchEmulator.from_sequence(seq, config=P.SimConfig(noise=("doppler", "dephasing")), evaluation_times=times).run()

@@ -110,3 +110,23 @@ def test_custom_waveform_optimisation_trace(cuda_device):
     ref = PINS["ka4_shape_opt"]
     assert abs(init - ref["initial_expectation"]) < 6e-5
     assert np.abs(np.array(losses) - np.array(ref["losses"][:8])).max() < 3e-6
+
+
+def test_dephasing_master_equation_optimisation_trace(cuda_device):
+    """basic_usage.ipynb section 2.5: the pulse-parameter optimisation of section 2.1 with `SimConfig(noise="dephasing",
+    dephasing_rate=2.0)` and `SolverType.DP5_ME` — the reference's stored initial expectation value and Adam loss trace pin
+    the master-equation path AND its gradients (collapse operator sqrt(rate/2) Z on every qubit, hamiltonian.py:108-116)."""
+    from pulser_diff_amd.simconfig import SimConfig
+
+    seq = _seq21(pl.Register.rectangle(1, 2, spacing=8, prefix="q"))
+    model = QuantumModel(seq, {"omega": torch.tensor([5.0], requires_grad=True), "area": torch.tensor([torch.pi], requires_grad=True)},
+                         constraints={"omega": {"min": 4.5, "max": 5.5}}, sampling_rate=0.5, solver=SolverType.DP5_ME,
+                         noise_config=SimConfig(noise="dephasing", dephasing_rate=2.0))
+    ref = PINS["ka_noisy_opt"]
+    init, losses = run_opt_loop(model, torch.optim.Adam(model.parameters(), lr=0.05), len(ref["losses"]))
+    assert abs(init - ref["initial_expectation"]) < 6e-5
+    assert len(losses) == len(ref["losses"])
+    assert np.abs(np.array(losses) - np.array(ref["losses"])).max() < 2e-6
+    params = dict(model.named_parameters())
+    assert abs(params["seq_param_values.omega"].item() - 5.5) < 1e-4
+    assert abs(params["seq_param_values.area"].item() - 1.7127) < 2e-4

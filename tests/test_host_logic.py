@@ -197,7 +197,10 @@ def test_emulator_validation_errors_match_the_reference():
     with pytest.raises(TypeError):
         P.TorchEmulator.from_sequence("not a sequence")
     with pytest.raises(NotImplementedError):
-        sim.set_config(P.SimConfig(noise="dephasing"))
+        sim.set_config(P.SimConfig(noise="leakage"))  # three-level leakage is not part of this backend
+    sim.set_config(P.SimConfig(noise="dephasing"))  # collapse-operator noise: accepted, run() switches to the master equation
+    assert sim._hamiltonian.config.noise_types == ("dephasing",)
+    sim.reset_config()
     sim.set_evaluation_times("Minimal")
     assert sim.evaluation_times.tolist() == [0.0, 1.6]
     sim.set_evaluation_times(0.5)

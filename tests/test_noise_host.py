@@ -75,8 +75,8 @@ def test_fixed_preparation_errors_and_config_merging():
     assert set(sim.config.noise) == {"SPAM", "doppler"}
     assert sim.config.eta == 0.2 and abs(sim.config.temperature - 30e-6) < 1e-18  # old SPAM parameters kept, doppler's added
     assert abs(sim._hamiltonian.config.temperature - 30.0) < 1e-9
-    with pytest.raises(NotImplementedError, match="collapse operators"):
-        sim.set_config(P.SimConfig(noise=("doppler", "depolarizing")))
+    with pytest.raises(NotImplementedError, match="leakage"):
+        sim.set_config(P.SimConfig(noise=("doppler", "leakage")))
     sim.reset_config()
     assert sim.config.noise == ()
 

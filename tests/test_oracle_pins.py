@@ -160,3 +160,34 @@ def test_duration_optimisation_envelopes_reproduce_notebook_value():
     st = R.krylov_map_dense(terms, R.all_ground_state(2), ts)
     e = R.expect(R.total_magnetization(2), st).real[-1]
     assert abs(e.item() - PINS["ka_duration_opt"]["initial_expectation"]) < 6e-5
+
+
+def test_master_equation_pin_dephasing_expectation_and_first_losses():
+    """basic_usage.ipynb section 2.5 (SolverType.DP5_ME, SimConfig(noise="dephasing", dephasing_rate=2.0)): the stored initial
+    expectation value -0.3802 pins the collapse-operator convention (sqrt(rate/2) Z on every qubit, hamiltonian.py:108-116) and
+    the Lindblad form; the first printed Adam losses pin its gradients (dense Magnus integrator, autograd)."""
+    pair = torch.tensor([[-4.0, 0.0], [4.0, 0.0]], dtype=torch.float64)
+    collapse = R.collapse_operators(2, {"dephasing": 2.0})
+    psi0 = R.all_ground_state(2)[:, 0]
+    rho0 = torch.outer(psi0, psi0.conj())
+    zd = R.total_magnetization_diag(2)
+    ref = PINS["ka_noisy_opt"]
+    # continuous-time solution (DOP853) at the notebook's initial parameters
+    seq = R.concat_pulses(_pulses_21(torch.tensor(5.0), F32_PI[0]))
+    terms = R.build_terms(seq, pair, 0.5)
+    ts = R.evaluation_times(seq.tot_duration, 0.5)
+    sol = R.lindblad_continuous_solution(terms, collapse, rho0.numpy(), ts.numpy()[[0, -1]], rtol=1e-10, atol=1e-12)
+    assert abs((np.diag(sol[-1]).real * zd.numpy()).sum() - ref["initial_expectation"]) < 6e-5
+    # two Adam steps through the differentiable integrator
+    omega = torch.tensor([5.0], requires_grad=True)
+    area = torch.tensor([torch.pi], requires_grad=True)
+
+    def model():
+        s = R.concat_pulses(_pulses_21(omega[0], area[0]))
+        t = R.build_terms(s, pair, 0.5)
+        e = R.evaluation_times(s.tot_duration, 0.5)
+        rho = R.lindblad_magnus_dense(t, collapse, rho0, torch.stack([e[0], e[-1]]), h_max=0.002)
+        return (torch.diagonal(rho[-1]).real * zd).sum()
+
+    losses = _adam_trace([omega, area], model, 0.05, 2, clamp=lambda: omega.clamp_(4.5, 5.5))
+    assert np.abs(np.array(losses) - np.array(ref["losses"][:2])).max() < 2e-6
