@@ -25,7 +25,7 @@ from torch import Tensor
 
 from . import pulser_adapter, pulses
 from .hamiltonian import COLLAPSE_NOISES, Hamiltonian
-from .lindblad import mesolve
+from .lindblad import MAX_ME_QUBITS, dissipator_block, doubled_tables, local_collapse_operators, mesolve
 from .result import SampledResult
 from .simconfig import SimConfig
 from .simresults import CoherentResults, NoisyResults, SimulationResults
@@ -336,9 +336,6 @@ class TorchEmulator:
             reps = [r for _, r in drawn]
         else:
             reps = [1] * self.config.runs
-        if solver == SolverType.DP5_ME:
-            raise NotImplementedError("Stochastic noise realisations (doppler / amplitude fluctuations / preparation errors) "
-                                      "combined with collapse-operator noise are not implemented: run them separately.")
         return self._run_noisy(psi0, solver, options, reps, bad_atom_configs, meas_errors)
 
     def _run_noisy(self, psi0: Tensor, solver: SolverType, options: dict, reps: list, bad_atom_configs,
@@ -353,10 +350,24 @@ class TorchEmulator:
         amp, det, amp_masks, det_masks = ham.noisy_batch_tables(loop_runs, bad_atom_configs)
         n, n_t = ham._size, int(self._eval_times_array.shape[0])
         dim = 2**n
-        spec = ProblemSpec(n, ham.dt, ham.n_samples, amp_masks, det_masks, solver=solver,
-                           tol=tolerance_from_options(options), store_states=True)
-        # bound the saved states of one batch (n_t x runs x 2^N amplitudes)
-        chunk = max(1, min(loop_runs, int(self._noisy_state_budget // max(n_t * dim * 16, 1))))
+        master = solver == SolverType.DP5_ME  # collapse operators on top: every realisation is a density matrix
+        u_pairs = ham.u_pairs.detach()
+        if master:
+            if n > MAX_ME_QUBITS:
+                raise ValueError(f"The master-equation solver keeps 4^N amplitudes; limited to {MAX_ME_QUBITS} qubits.")
+            amp, det, u_pairs, amp_masks, det_masks = doubled_tables(amp, det, u_pairs, amp_masks, det_masks, n)
+            block = dissipator_block(local_collapse_operators(ham.config))
+            spec = ProblemSpec(2 * n, ham.dt, ham.n_samples, amp_masks, det_masks, solver=SolverType.DP5_SE,
+                               tol=tolerance_from_options(options), store_states=True,
+                               pair_terms=tuple((j, n + j, block) for j in range(n)))
+            ket = psi0.to(dev)[:, 0]
+            start = torch.outer(ket, ket.conj()).reshape(1, dim * dim)
+        else:
+            spec = ProblemSpec(n, ham.dt, ham.n_samples, amp_masks, det_masks, solver=solver,
+                               tol=tolerance_from_options(options), store_states=True)
+            start = psi0.to(dev).T.contiguous()
+        # bound the saved states of one batch (n_t x runs x 2^N, or 4^N, amplitudes)
+        chunk = max(1, min(loop_runs, int(self._noisy_state_budget // max(n_t * start.shape[1] * 16, 1))))
         eps = meas_errors["epsilon"] if meas_errors else 0.0
         eps_p = meas_errors["epsilon_prime"] if meas_errors else 0.0
         bit_weights = (1 << torch.arange(n, device=dev, dtype=torch.int64))
@@ -365,9 +376,11 @@ class TorchEmulator:
         for r0 in range(0, loop_runs, chunk):
             r1 = min(loop_runs, r0 + chunk)
             with torch.no_grad():
-                states, _ = evolve(amp[r0:r1], det[r0:r1], ham.u_pairs.detach(), tsave,
-                                   psi0.to(dev).T.contiguous().repeat(r1 - r0, 1), spec, None)
-                probs = states.real**2 + states.imag**2  # (n_t, runs, dim), basis order r = 0, g = 1
+                states, _ = evolve(amp[r0:r1], det[r0:r1], u_pairs, tsave, start.repeat(r1 - r0, 1), spec, None)
+                if master:  # populations = diagonal of rho
+                    probs = states.reshape(n_t, r1 - r0, dim, dim).diagonal(dim1=2, dim2=3).real.clamp_min(0.0)
+                else:
+                    probs = states.real**2 + states.imag**2  # (n_t, runs, dim), basis order r = 0, g = 1
                 del states
                 for b in range(r1 - r0):
                     n_shots = self.config.samples_per_run * reps[r0 + b]

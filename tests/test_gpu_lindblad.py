@@ -129,5 +129,12 @@ def test_emulator_runs_the_master_equation_and_returns_density_results(cuda_devi
     pure = P.TorchEmulator.from_sequence(seq, evaluation_times=times).run(solver=SolverType.DP5_ME)
     ket = clean.states[-1, :, 0]
     assert (pure.states[-1, :, :, 0] - torch.outer(ket, ket.conj())).abs().max().item() < 1e-8
-    with pytest.raises(NotImplementedError, match="combined with collapse-operator noise"):
-        P.TorchEmulator.from_sequence(seq, config=P.SimConfig(noise=("doppler", "dephasing")), evaluation_times=times).run()
+    # collapse noise combined with stochastic realisations: every realisation is a density matrix of one batched solve;
+    # with vanishing Doppler width the sampled populations are those of the dephasing-only run
+    torch.manual_seed(5)
+    cfg2 = P.SimConfig(noise=("doppler", "dephasing"), temperature=0.0, dephasing_rate=1.0, runs=8, samples_per_run=500)
+    noisy = P.TorchEmulator.from_sequence(seq, config=cfg2, evaluation_times=times).run()
+    deph = P.TorchEmulator.from_sequence(seq, config=P.SimConfig(noise="dephasing", dephasing_rate=1.0), evaluation_times=times).run()
+    zd = DiagonalObservable(total_magnetization_diag(n))
+    assert noisy.n_measures == 4000
+    assert np.abs(noisy.expect([zd])[0].numpy() - deph.expect([zd])[0].real.cpu().numpy()).max() < 5 * np.sqrt(n) / np.sqrt(4000)
