@@ -24,6 +24,26 @@ struct PersistFactor {
     int pad;
 };
 
+// dense two-qubit terms with the whole register in the LDS tile: sum_p sum_s T_p[4*own + s] * tile[x with the pair's bits = s]
+__device__ __forceinline__ double2 pair_apply_tile(const PairArgs& pa, int which, const double2* stab /* LDS copy of pa.tab */,
+                                                    const double2* tile, unsigned x) {
+    double2 acc = make_double2(0.0, 0.0);
+    for (int t = 0; t < pa.n; ++t) {
+        const uint32_t ma = pa.ma[t], mb = pa.mb[t];
+        const int own = ((x & ma) ? 2 : 0) | ((x & mb) ? 1 : 0);
+        const unsigned base = x & ~(ma | mb);
+        const double2* row = stab + (t * 2 + which) * 16 + own * 4;
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const double2 c = row[sidx];
+            const double2 q = tile[base | ((sidx & 2) ? ma : 0u) | ((sidx & 1) ? mb : 0u)];
+            acc.x += c.x * q.x - c.y * q.y;
+            acc.y += c.x * q.y + c.y * q.x;
+        }
+    }
+    return acc;
+}
+
 struct PersistArgs {
     const double2* psi0;      // [B][dim]
     double2* states;          // [n_tsave][B][dim] or nullptr
@@ -41,6 +61,7 @@ struct PersistArgs {
     uint32_t amask[kMaxGroups];
     uint32_t dmask[kMaxGroups];
     int dcnt[kMaxGroups];
+    PairArgs pair;
 };
 
 // stage factors [f0, f0 + count) and (when they fit) their coefficient records; all threads of the workgroup take part
@@ -68,6 +89,8 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist(P
     __shared__ double red[NW];
     __shared__ PersistFactor sfac[kStageChunk];
     __shared__ double scoef[SMALLG ? kStageChunk : 1][kStageNC];
+    __shared__ double2 spair[RYDIFF_MAX_PAIR_TERMS * 32];
+    for (int i = int(threadIdx.x); i < a.pair.n * 32; i += NTL) spair[i] = a.pair.tab[i];  // published by the first barrier
     const unsigned tid0 = threadIdx.x;
     const unsigned tid = tid0;
     const bool active = tid < NT;  // tiny registers run on a partial first wave; the rest only helps staging
@@ -149,6 +172,14 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist(P
             } else {
                 for (int g = 0; g < a.ga; ++g) amp_group(g);
             }
+            if (a.pair.n) {  // beta * (dense two-qubit terms)
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const double2 pv = pair_apply_tile(a.pair, 0, spair, tile, unsigned(r) * NT + tid);
+                    q[r].x += pf.br * pv.x - pf.bi * pv.y;
+                    q[r].y += pf.br * pv.y + pf.bi * pv.x;
+                }
+            }
         }
         __syncthreads();  // every partner read of the old vector is done
         if (active) {
@@ -224,6 +255,7 @@ struct PersistBwdArgs {
     uint32_t amask[kPersistGroups];
     uint32_t dmask[kPersistGroups];
     int dcnt[kPersistGroups];
+    PairArgs pair;
 };
 
 template <int LT, int LGT, bool CPLX>
@@ -241,6 +273,8 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist_b
     __shared__ PersistFactor sfac[kStageChunk];
     __shared__ double scoef[kStageChunk][kStageNC];
     __shared__ int sflag[kStageChunk];
+    __shared__ double2 spair[RYDIFF_MAX_PAIR_TERMS * 32];
+    for (int i = int(threadIdx.x); i < a.pair.n * 32; i += NTL) spair[i] = a.pair.tab[i];  // published by the first refill barrier
     const unsigned tid0 = threadIdx.x;
     const bool active = tid0 < NT;
     const int b = blockIdx.x;
@@ -378,6 +412,14 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist_b
                         }
                     }
                 }
+                if (a.pair.n) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const double2 pv = pair_apply_tile(a.pair, 0, spair, tile, unsigned(r) * NT + tid);
+                        q[r].x += pf.br * pv.x - pf.bi * pv.y;
+                        q[r].y += pf.br * pv.y + pf.bi * pv.x;
+                    }
+                }
             }
             __syncthreads();
             if (active) {
@@ -447,7 +489,15 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist_b
                         acc_im[g] += pf.br * z2i + pf.bi * z2r;
                     }
                 }
-                if (stage_end && a.want_tau) {  // dL/dtau = Im<mu, H x_out> = Im<H mu, x_out>
+                if (a.pair.n) {  // the generator is M = K + T with K Hermitian: M^dagger mu = K mu + T^dagger mu
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const double2 pv = pair_apply_tile(a.pair, 1, spair, tile, unsigned(r) * NT + tid);
+                        hm[r].x += pv.x;
+                        hm[r].y += pv.y;
+                    }
+                }
+                if (stage_end && a.want_tau) {  // dL/dtau = Im<mu, M x_out> = Im<M^dagger mu, x_out>
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const double2 o = (i == M - 1) ? (KEEPX ? xend[r] : state_elem(k1, r)) : park_load(i, unsigned(r) * NT + tid);

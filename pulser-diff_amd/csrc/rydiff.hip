@@ -1393,7 +1393,7 @@ int run_chain_bwd(const Runtime& rt, char* ws, const std::vector<ChainItem>& ite
 }
 
 // ---- persistent small-N forward (k_persist) ------------------------------------------------------------------------
-bool persist_enabled(const Runtime& rt) { return g_kernel_variant != 1 && rt.pl.N <= kTileBits && rt.pl.n_pair == 0; }
+bool persist_enabled(const Runtime& rt) { return g_kernel_variant != 1 && rt.pl.N <= kTileBits; }
 
 template <int LT, bool CPLX>
 int launch_persist_t(const PersistArgs& pa, int B, hipStream_t stream) {
@@ -1581,6 +1581,7 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
         pa.dim = uint32_t(pl.dim);
         pa.ga = pl.ga.n;
         pa.gd = pl.gd.n;
+        pa.pair = rt.parg;
         for (int g = 0; g < pl.ga.n; ++g) pa.amask[g] = pl.ga.amp_index_mask[g];
         for (int g = 0; g < pl.gd.n; ++g) {
             pa.dmask[g] = pl.gd.amp_index_mask[g];
@@ -1734,6 +1735,7 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
         pa.dim = uint32_t(pl.dim);
         pa.ga = pl.ga.n;
         pa.gd = pl.gd.n;
+        pa.pair = rt.parg;
         for (int g = 0; g < pl.ga.n; ++g) pa.amask[g] = pl.ga.amp_index_mask[g];
         for (int g = 0; g < pl.gd.n; ++g) {
             pa.dmask[g] = pl.gd.amp_index_mask[g];
