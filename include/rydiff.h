@@ -88,7 +88,8 @@ typedef struct RydProblem {
      * column qubits), the commutator is an ordinary structured "Hamiltonian" on it, and every collapse operator acting
      * on qubit j contributes a constant 4x4 block on the pair (row qubit j, column qubit j):
      *   (M v)[x] += sum_{s=0..3} T_p[4*own + s] * v[x with the bits of qubits (a_p, b_p) set to s],
-     * own / s = 2*bit(a_p) + bit(b_p).  M need not be Hermitian.  Problems with pair terms run on the direct kernels. */
+     * own / s = 2*bit(a_p) + bit(b_p).  M need not be Hermitian.  Problems with pair terms run on the persistent (N <= 12)
+     * or direct kernels. */
     int32_t n_pair_terms;          /* 0..RYDIFF_MAX_PAIR_TERMS */
     const uint32_t* pair_qubits;   /* HOST [n_pair_terms][2]: (a_p, b_p), a_p != b_p */
     const double* pair_tables;     /* HOST complex128 as (re, im) [n_pair_terms][16] */

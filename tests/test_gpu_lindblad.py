@@ -138,3 +138,29 @@ def test_emulator_runs_the_master_equation_and_returns_density_results(cuda_devi
     zd = DiagonalObservable(total_magnetization_diag(n))
     assert noisy.n_measures == 4000
     assert np.abs(noisy.expect([zd])[0].numpy() - deph.expect([zd])[0].real.cpu().numpy()).max() < 5 * np.sqrt(n) / np.sqrt(4000)
+
+
+def test_pair_terms_on_direct_and_persistent_kernels_agree(cuda_device):
+    """The dense pair terms exist in two kernel families: the persistent one-launch kernels (doubled register <= 12 qubits)
+    and the one-amplitude-per-thread kernels (anything larger, or kernel variant 1).  Same density matrices, same gradients."""
+    from pulser_diff_amd import _native
+
+    n = 3
+    terms = random_terms(n, 17, 0.004, seed=91, local=True)
+    cfg = SimConfig(noise=("relaxation", "depolarizing"), relaxation_rate=0.7, depolarizing_rate=0.2)
+    tsave0 = torch.tensor([0.0, 0.013, 0.04, 0.06], dtype=torch.float64)
+    psi0 = R.all_ground_state(n)
+    out = {}
+    for variant in (1, 0):
+        _native.set_kernel_variant(variant)
+        try:
+            ham = _ham_like(terms, cuda_device, requires_grad=True)
+            ts = tsave0.clone().requires_grad_(True)
+            rho, _ = mesolve(ham, psi0.to(cuda_device), ts, cfg.to_noise_model())
+            (torch.diagonal(rho[..., 0], dim1=1, dim2=2).real * torch.linspace(-1, 1, 2**n, device=cuda_device)[None]).sum().backward()
+            out[variant] = [rho.detach().cpu().numpy(), ham.amp_tables.grad.cpu().numpy(), ham.det_tables.grad.cpu().numpy(),
+                            ham.u_pairs.grad.cpu().numpy(), ts.grad.numpy()]
+        finally:
+            _native.set_kernel_variant(0)
+    for name, ref, got in zip(("rho", "amp", "det", "u", "tsave"), out[1], out[0]):
+        assert rel_err(got, ref) < 1e-10, name
