@@ -25,7 +25,7 @@ from torch import Tensor
 
 from . import pulser_adapter, pulses
 from .hamiltonian import COLLAPSE_NOISES, Hamiltonian
-from .lindblad import MAX_ME_QUBITS, dissipator_block, doubled_tables, local_collapse_operators, mesolve
+from .lindblad import MAX_ME_QUBITS, ME_DEFAULT_TOL, dissipator_block, doubled_tables, local_collapse_operators, mesolve
 from .result import SampledResult
 from .simconfig import SimConfig
 from .simresults import CoherentResults, NoisyResults, SimulationResults
@@ -358,7 +358,7 @@ class TorchEmulator:
             amp, det, u_pairs, amp_masks, det_masks = doubled_tables(amp, det, u_pairs, amp_masks, det_masks, n)
             block = dissipator_block(local_collapse_operators(ham.config))
             spec = ProblemSpec(2 * n, ham.dt, ham.n_samples, amp_masks, det_masks, solver=SolverType.DP5_SE,
-                               tol=tolerance_from_options(options), store_states=True,
+                               tol=tolerance_from_options(options) or ME_DEFAULT_TOL, store_states=True,
                                pair_terms=tuple((j, n + j, block) for j in range(n)))
             ket = psi0.to(dev)[:, 0]
             start = torch.outer(ket, ket.conj()).reshape(1, dim * dim)

@@ -102,7 +102,9 @@ inline bool build_groups(int N, int n_terms, const uint32_t* masks, Groups& g, s
     return true;
 }
 
-inline bool build_plan(const RydProblem* p, Plan& pl, std::string& err) {
+// `width`: half spectral width of the generator when it is already known (<= 0: not yet) — the continuous solver's
+// sub-step shrinks with it.
+inline bool build_plan(const RydProblem* p, Plan& pl, std::string& err, double width = -1.0) {
     if (!p) {
         err = "null problem";
         return false;
@@ -231,7 +233,12 @@ inline bool build_plan(const RydProblem* p, Plan& pl, std::string& err) {
     };
     // continuous-time solver: largest sub-step of the 4th-order commutator-free Magnus scheme.  Calibrated on the
     // reference's own workloads (tests/test_gpu_dp5.py): 2.5 ns keeps the global error below ~2e-10; error ~ h^4.
-    const double h_max = 2.5e-3 * std::pow(std::min(std::max(pl.ode_tol, 1e-14), 1e-4) / 1e-10, 0.25);
+    // The leading error term carries two powers of the generator's size ([A,[A,A']]), so beyond the calibrated range
+    // (half width ~1e2 rad/us) the step shrinks like width^-1/2 — this is what keeps strongly dissipative master-equation
+    // runs (large pair terms) and strongly interacting registers at the same accuracy.
+    constexpr double kMagnusWidthRef = 128.0;
+    const double h_max = 2.5e-3 * std::pow(std::min(std::max(pl.ode_tol, 1e-14), 1e-4) / 1e-10, 0.25) *
+                         (width > kMagnusWidthRef ? std::sqrt(kMagnusWidthRef / width) : 1.0);
     for (int k = 0; k < pl.T; ++k) {
         pl.step_begin[k] = int(pl.stages.size());
         if (pl.solver == RYDIFF_SOLVER_KRYLOV_SE) {

@@ -732,6 +732,9 @@ void fill_group_args(const Plan& pl, GroupArgs& g) {
     }
 }
 
+// half width of the generator's numerical range (same widening as finish_runtime)
+double generator_half_width(const Plan& pl, double lo, double hi) { return std::max(0.5 * (hi - lo), 1e-9) + pl.pair_radius; }
+
 // apply spectral bounds: sub-steps, design rho, polynomial, factor counts
 int finish_runtime(Runtime& rt, double lo, double hi) {
     Plan& pl = rt.pl;
@@ -842,6 +845,8 @@ int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_
         int rc = run_stats(p, rt.pl, workspace, stream, lo, hi, rt.flags);
         if (rc) return rc;
     }
+    // the stage list of the continuous solver depends on the spectral width: rebuild it now that the width is known
+    if (!build_plan(p, rt.pl, err, generator_half_width(rt.pl, lo, hi))) return fail(RYDIFF_EINVAL, err);
     int rc = finish_runtime(rt, lo, hi);
     if (rc) return rc;
     Plan& pl = rt.pl;
@@ -1519,6 +1524,7 @@ int rydiff_plan(const RydProblem* p, int need_tape, int need_backward, void* scr
     double lo, hi;
     int rc = run_stats(p, rt.pl, scratch, stream, lo, hi, rt.flags);
     if (rc) return rc;
+    if (!build_plan(p, rt.pl, err, generator_half_width(rt.pl, lo, hi))) return fail(RYDIFF_EINVAL, err);
     rc = finish_runtime(rt, lo, hi);
     if (rc) return rc;
     int tm = need_tape;

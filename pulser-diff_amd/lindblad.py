@@ -30,6 +30,7 @@ from .solver import ProblemSpec, SolverType, evolve, tolerance_from_options
 
 CD = torch.complex128
 MAX_ME_QUBITS = 12  # 4^12 amplitudes = 256 MiB per density matrix
+ME_DEFAULT_TOL = 1e-10
 
 _Z = np.array([[1, 0], [0, -1]], dtype=complex)        # r = |0>, g = |1>; Z|r> = +|r> (utils.py ZMAT)
 _X = np.array([[0, 1], [1, 0]], dtype=complex)
@@ -99,8 +100,10 @@ def mesolve(ham, psi0: Tensor, tsave: Tensor, noise: NoiseModel, options: Option
     amp2, det2, u2, am2, dm2 = doubled_tables(ham.amp_tables, ham.det_tables, ham.u_pairs, ham.amp_masks, ham.det_masks, n)
     block = dissipator_block(local_collapse_operators(noise))
     pair_terms = tuple((j, n + j, block) for j in range(n)) if np.any(block != 0) else ()
-    spec = ProblemSpec(2 * n, ham.dt, ham.n_samples, am2, dm2, solver=SolverType.DP5_SE, tol=tolerance_from_options(options),
-                       store_states=True, pair_terms=pair_terms)
+    # default accuracy target one decade below the ket solver's: the calibration of the Magnus step is a little optimistic
+    # for non-normal (dissipative) generators
+    spec = ProblemSpec(2 * n, ham.dt, ham.n_samples, am2, dm2, solver=SolverType.DP5_SE,
+                       tol=tolerance_from_options(options) or ME_DEFAULT_TOL, store_states=True, pair_terms=pair_terms)
     psi = psi0.to(dev, CD)
     if psi.ndim == 1:
         psi = psi.unsqueeze(1)
