@@ -225,15 +225,18 @@ class TorchEmulator:
                 raise ValueError("Provided evaluation-time list extends " "further than sequence duration.")
             if torch.min(torch.as_tensor(value)) < 0:
                 raise ValueError("Provided evaluation-time list contains " "negative values.")
-            eval_times = torch.as_tensor(value, dtype=torch.float64)
+            eval_times = torch.as_tensor(value)  # the union below is taken in the caller's dtype, like the reference does
+            if not eval_times.is_floating_point():
+                eval_times = eval_times.to(torch.float64)
         else:
             raise ValueError(
                 "Wrong evaluation time label. It should "
                 "be `Full`, `Minimal`, an array of times or a " + "float between 0 and 1."
             )
         self._eval_times_array = (
-            torch.cat([eval_times, torch.tensor([0.0, self._tot_duration / 1000], dtype=eval_times.dtype)])
+            torch.cat([eval_times.detach().cpu(), torch.tensor([0.0, self._tot_duration / 1000], dtype=eval_times.dtype)])
             .unique()
+            .to(torch.float64)
             .requires_grad_(False)
         )
         self._eval_times_instruction = value

@@ -83,6 +83,8 @@ def expect(obs, states: Tensor) -> Tensor:
         if states.ndim != 3:
             raise ValueError("DiagonalObservable expects kets (n_t, dim, B) or density matrices (n_t, dim, dim, B).")
         return (states.abs() ** 2 * d[None, :, None]).sum(dim=(1, 2)).to(states.dtype)
+    if states.is_sparse:  # a sparse density matrix (tests/test_noise.py:121-125): small, densify
+        states = states.to_dense()
     if obs.is_sparse:
         if states.ndim == 3:
             st = states.squeeze(-1)
