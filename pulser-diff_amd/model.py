@@ -101,8 +101,9 @@ class QuantumModel(Module):
 
     def _create_opt_sequence(self, values: dict) -> pl.Sequence:
         """model.py:184-206 + 324-368: one global channel, every constant pulse replaced by its tanh envelope."""
-        if len(self._seq.declared_channels) != 1:
-            raise NotImplementedError("Duration optimisation supports sequences with a single global channel.")
+        used = [ch for ch, items in self._seq._schedule.items() if any(it[0] == "pulse" for it in items)]
+        if len(used) != 1 or self._seq.declared_channels[used[0]].addressing != "Global":
+            raise NotImplementedError("Duration optimisation supports pulses on a single global channel.")
         total = self._get_total_duration(values)
         t = torch.arange(total, dtype=torch.float64)
         amp = torch.zeros(total, dtype=torch.float64)
@@ -123,7 +124,7 @@ class QuantumModel(Module):
             phase = phase + constant_waveform(ti, tf, pl._t(ph).reshape(()))(t)
             ti = tf
         seq_opt = pl.Sequence(self.register, self.device)
-        (name, _), = self._seq.declared_channels.items()
+        name = used[0]
         seq_opt.declare_channel(name, "rydberg_global")
         seq_opt.add(pl.Pulse(pl.CustomWaveform(amp), pl.CustomWaveform(det), phase), name)
         return seq_opt
