@@ -1,7 +1,7 @@
 """Randomised A/B sweep (not part of the test suite; run on a GPU box): the automatically selected kernels (persistent /
 chained tiles / three layouts / full or step tape) against the one-amplitude-per-thread kernels on random problems —
 register size, term structure (global / several local channels, real or complex drives), batch with shared or per-trajectory
-tables, solver, irregular save times, every gradient.   python tools/fuzz_parity.py [n_cases] [seed] [max_qubits]"""
+tables, solver, irregular save times, every gradient.   python tools/fuzz_parity.py [n_cases] [seed] [max_qubits] [min_qubits]"""
 import sys
 from pathlib import Path
 
@@ -15,11 +15,12 @@ from pulser_diff_amd.solver import ProblemSpec, SolverType, evolve
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 max_q = int(sys.argv[3]) if len(sys.argv) > 3 else 17
+min_q = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 rng = np.random.default_rng(seed)
 dev = torch.device("cuda")
 worst, fails = 0.0, 0
 for case in range(n_cases):
-    n = int(rng.integers(1, max_q + 1))
+    n = int(rng.integers(min_q, max_q + 1))
     ns = int(rng.integers(6, 14))
     dt = float(rng.choice([0.001, 0.002, 0.004]))
     batch = int(rng.choice([1, 1, 2, 3])) if n <= 14 else 1
