@@ -115,7 +115,7 @@ typedef struct RydPlanInfo {
  *                        states_out == NULL but wants gradients);
  *                  2: FULL tape — the output of every factor pass is kept ((total_factors+1) states), so the adjoint
  *                        sweep recomputes nothing.  Sized for 288 GB of HBM: 156 GiB at N=20, T=1000.  Falls back to 1
- *                        where the chained tile kernels do not apply (N <= 12 or N > 24).
+ *                        where the chained tile kernels do not apply (N <= 12 or N > 28, or with pair terms).
  *   need_backward  != 0: reserve the backward-sweep buffers too
  *   scratch        DEVICE, >= RYDIFF_PLAN_SCRATCH_BYTES */
 int rydiff_plan(const RydProblem* p, int need_tape, int need_backward, void* scratch, void* stream, RydPlanInfo* info);
