@@ -1,5 +1,5 @@
 """Phase timeline of the chained forward pass (tuning builds with -DRYDIFF_TIMELINE only):
-RYDIFF_LIB=abl/lib_timeline.so python tools/timeline.py [N]"""
+make -C pulser-diff_amd/csrc timeline && RYDIFF_LIB=pulser-diff_amd/csrc/librydiff_timeline.so python tools/timeline.py [N]"""
 import ctypes, sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))

@@ -1,5 +1,5 @@
 """Phase timeline of the chained ADJOINT pass (tuning builds with -DRYDIFF_TIMELINE only):
-RYDIFF_LIB=abl/lib_timeline.so python tools/timeline_bwd.py"""
+make -C pulser-diff_amd/csrc timeline && RYDIFF_LIB=pulser-diff_amd/csrc/librydiff_timeline.so python tools/timeline_bwd.py"""
 import ctypes, runpy, sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
