@@ -17,7 +17,11 @@
 // read consecutive 16-byte slots of a permuted 1 KiB span).
 #pragma once
 
-constexpr int kTileBits = 12;
+#ifndef RYDIFF_TILE_BITS
+#define RYDIFF_TILE_BITS 12
+#endif
+constexpr int kTileBits = RYDIFF_TILE_BITS;
+constexpr unsigned kTileAmps = 1u << kTileBits;
 
 // Streaming store: the vectors written by a pass are read next by OTHER workgroups in the other tile layout, never by
 // this one, so there is no point keeping the lines dirty in this XCD's L2 until the end-of-kernel write-back.

@@ -329,7 +329,7 @@ inline size_t carve(Plan& pl, int tape_mode, bool need_backward, int chain_slots
     pl.off_pp0 = take(pl.state_bytes);  // partial vectors of the chained passes
     pl.off_pp1 = take(pl.state_bytes);
     // split interaction diagonal for the two tile layouts: utt[2][4096] + vr[2][tiles][16]
-    pl.off_split = take(3 * (4096 + (pl.dim >> 12 ? (pl.dim >> 12) : 1) * 16) * sizeof(double));  // up to three tile layouts
+    pl.off_split = take(3 * (4096 + (pl.dim >> 11 ? (pl.dim >> 11) : 1) * 16) * sizeof(double));  // up to three tile layouts
     pl.off_ptable = take(pl.ptable_bytes);
     pl.off_pair = take(size_t(pl.n_pair) * 64 * sizeof(double));
     pl.total_fwd = off;

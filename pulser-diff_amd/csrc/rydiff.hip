@@ -37,7 +37,10 @@ constexpr int kMaxRemote = 6;  // up to 2^6 GPUs in a state-sharded run
 
 static thread_local std::string g_last_error;
 static int g_kernel_variant = 0;
-constexpr int kTileBitsHost = 12;
+#ifndef RYDIFF_TILE_BITS
+#define RYDIFF_TILE_BITS 12
+#endif
+constexpr int kTileBitsHost = RYDIFF_TILE_BITS;
 
 static int fail(int code, const std::string& msg) {
     g_last_error = msg;
@@ -174,7 +177,7 @@ __global__ void k_build_udiag(double* __restrict__ udiag, const double* __restri
 //   U(x) = utt[i] + vr[t][12] + sum_{tile bits a with n_a(i)=1} vr[t][a],   x = x(t, i)
 __global__ void k_build_split(double* __restrict__ utt, double* __restrict__ vr, const double* __restrict__ u_pairs,
                               int N, int lo, int hs, int hb, unsigned tiles) {
-    constexpr int LT = 12;
+    constexpr int LT = kTileBitsHost;
     const unsigned id = blockIdx.x * blockDim.x + threadIdx.x;
     auto gbit = [&](int b) { return b < lo ? b : hs + (b - lo); };          // tile bit -> index bit
     auto upair = [&](int ib, int jb) {                                       // index bits -> U_ij
@@ -898,14 +901,14 @@ int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_
     } else {
         HIP_TRY(hipMemsetAsync(udiag, 0, pl.dim * sizeof(double), stream));
     }
-    if (pl.N > 12 && pl.N <= 28) {  // split diagonal for the tile layouts of the chained passes
-        const unsigned tiles = unsigned(pl.dim >> 12);
+    if (pl.N > kTileBits && pl.N <= 28) {  // split diagonal for the tile layouts of the chained passes
+        const unsigned tiles = unsigned(pl.dim >> kTileBits);
         double* split = reinterpret_cast<double*>(ws + pl.off_split);
-        const size_t per_layout = 4096 + size_t(tiles) * 16;
+        const size_t per_layout = kTileAmps + size_t(tiles) * 16;
         for (int l = 0; l < chain_layout_count(pl.N); ++l) {
             const LayoutDesc d = chain_layout(pl.N, l);
             double* utt = split + l * per_layout;
-            hipLaunchKernelGGL(k_build_split, dim3((4096 + tiles + 255) / 256), dim3(256), 0, stream, utt, utt + 4096,
+            hipLaunchKernelGGL(k_build_split, dim3((kTileAmps + tiles + 255) / 256), dim3(256), 0, stream, utt, utt + kTileAmps,
                                p->u_pairs, pl.N, d.lo, d.hs, d.hb, tiles);
             LAUNCH_CHECK();
         }
@@ -1080,10 +1083,10 @@ int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, hipStream_t s
     ca.v_out = cs.v_out;
     ca.q_out = cs.q_out;
     {
-        const size_t per_layout = 4096 + size_t(pl.dim >> kTileBits) * 16;
+        const size_t per_layout = kTileAmps + size_t(pl.dim >> kTileBits) * 16;
         const double* split = reinterpret_cast<const double*>(ws + pl.off_split) + size_t(cs.layout) * per_layout;
         ca.utt = split;
-        ca.vr = split + 4096;
+        ca.vr = split + kTileAmps;
     }
     const double* coef = reinterpret_cast<const double*>(ws + pl.off_coef);
     ca.coef_fin = coef + size_t(std::max(cs.fin_stage, 0)) * pl.NC;
@@ -1179,10 +1182,10 @@ int launch_chain2(const Runtime& rt, char* ws, const ChainStep& cs, hipStream_t 
     ca.v_out = cs.v_out;
     ca.q_out = cs.q_out;
     {
-        const size_t per_layout = 4096 + size_t(pl.dim >> kTileBits) * 16;
+        const size_t per_layout = kTileAmps + size_t(pl.dim >> kTileBits) * 16;
         const double* split = reinterpret_cast<const double*>(ws + pl.off_split) + size_t(cs.layout) * per_layout;
         ca.utt = split;
-        ca.vr = split + 4096;
+        ca.vr = split + kTileAmps;
     }
     const double* coef = reinterpret_cast<const double*>(ws + pl.off_coef);
     ca.coef_fin = coef + size_t(std::max(cs.fin_stage, 0)) * pl.NC;
