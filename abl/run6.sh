@@ -1,0 +1,4 @@
+cd /root/repo
+echo "variant 8 (LDS tile)"; QUBITS=1,2,4,6 RYDIFF_VARIANT=8 python tools/time_small.py 2>&1 | grep N=
+echo "lanes"; QUBITS=1,2,3,4,5,6 python tools/time_small.py 2>&1 | grep N=
+python -m pytest tests -m gpu -x -q 2>&1 | tail -15

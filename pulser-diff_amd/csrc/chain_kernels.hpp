@@ -173,6 +173,59 @@ __device__ __forceinline__ void partner_sums(const double2* __restrict__ tile, c
     }
 }
 
+// ---- registers of ONE wave as the tile (2^LT <= 64 amplitudes, one per lane): partners come through DPP lane exchanges
+// (bits 0..3: quad permutes / row rotates, no LDS at all) or ds_bpermute (bits 4, 5) — no tile write, no barrier.
+template <int CTRL, int BANK>
+__device__ __forceinline__ int dpp_mov(int old, int src) {
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xF, BANK, false);
+}
+
+template <int B>
+__device__ __forceinline__ int lane_xor_i32(int w) {
+    if constexpr (B == 0) return dpp_mov<0xB1, 0xF>(0, w);        // quad_perm [1,0,3,2]
+    else if constexpr (B == 1) return dpp_mov<0x4E, 0xF>(0, w);   // quad_perm [2,3,0,1]
+    else if constexpr (B == 2) {                                   // lanes with bit 2 set take lane-4 (row_ror:4), the others lane+4 (row_ror:12)
+        const int r = dpp_mov<0x124, 0xA>(0, w);
+        return dpp_mov<0x12C, 0x5>(r, w);
+    } else if constexpr (B == 3) return dpp_mov<0x128, 0xF>(0, w);  // row_ror:8
+    else return __shfl_xor(w, 1 << B, 64);
+}
+
+template <int B>
+__device__ __forceinline__ double2 lane_xor(const double2& v) {
+    const int a0 = lane_xor_i32<B>(__double2loint(v.x)), a1 = lane_xor_i32<B>(__double2hiint(v.x));
+    const int b0 = lane_xor_i32<B>(__double2loint(v.y)), b1 = lane_xor_i32<B>(__double2hiint(v.y));
+    return make_double2(__hiloint2double(a1, a0), __hiloint2double(b1, b0));
+}
+
+template <int LT, bool CPLX>
+__device__ __forceinline__ void partner_sums_lanes(const double2& own, uint32_t mask, unsigned tid, double2& ts, double2& ds) {
+    static_assert(LT <= 6, "one amplitude per lane");
+    ts = make_double2(0.0, 0.0);
+    ds = make_double2(0.0, 0.0);
+    auto bit = [&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        if constexpr (b < LT) {
+            if (mask >> b & 1u) {  // wave-uniform
+                const double2 q = lane_xor<b>(own);
+                ts.x += q.x;
+                ts.y += q.y;
+                if (CPLX) {
+                    const double sgn = (tid >> b & 1u) ? 1.0 : -1.0;
+                    ds.x = fma(sgn, q.x, ds.x);
+                    ds.y = fma(sgn, q.y, ds.y);
+                }
+            }
+        }
+    };
+    bit(std::integral_constant<int, 0>{});
+    bit(std::integral_constant<int, 1>{});
+    bit(std::integral_constant<int, 2>{});
+    bit(std::integral_constant<int, 3>{});
+    bit(std::integral_constant<int, 4>{});
+    bit(std::integral_constant<int, 5>{});
+}
+
 #ifdef RYDIFF_TIMELINE
 __device__ unsigned long long g_timeline[4096 * 8];  // tuning builds: per-workgroup phase timestamps of the last launch
 #define RYDIFF_TL(slot)                                                                                   \

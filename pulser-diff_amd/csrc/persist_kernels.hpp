@@ -97,6 +97,9 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist(P
     const int b = blockIdx.x;
     const size_t boff = size_t(b) * a.dim;
     const double* __restrict__ coef_b = a.coef + size_t(b) * a.coef_bstride;
+    // up to 6 qubits the state is one amplitude per lane of ONE wave: partners through lane exchanges, the LDS tile and
+    // its two barriers per factor are only kept for the dense pair terms
+    const bool lanes = LT <= 6 && a.pair.n == 0;
     double2 v[R];
     double ud[R], ob0[R];
 #pragma unroll
@@ -152,7 +155,12 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist(P
             }
             auto amp_group = [&](int g) {
                 double2 ts[R], ds[R];
-                partner_sums<LT, LGT, CPLX>(tile, v, a.amask[g], tid, ts, ds);
+                if constexpr (LT <= 6) {
+                    if (lanes) partner_sums_lanes<LT, CPLX>(v[0], a.amask[g], tid, ts[0], ds[0]);
+                    else partner_sums<LT, LGT, CPLX>(tile, v, a.amask[g], tid, ts, ds);
+                } else {
+                    partner_sums<LT, LGT, CPLX>(tile, v, a.amask[g], tid, ts, ds);
+                }
                 const double cr = cf(g), ci = cf(a.ga + g);
                 const double k1r = pf.br * cr, k1i = pf.bi * cr, k2r = -pf.bi * ci, k2i = pf.br * ci;
 #pragma unroll
@@ -181,12 +189,12 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist(P
                 }
             }
         }
-        __syncthreads();  // every partner read of the old vector is done
+        if (!lanes) __syncthreads();  // every partner read of the old vector is done
         if (active) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 v[r] = q[r];
-                tile[unsigned(r) * NT + tid] = q[r];
+                if (!lanes) tile[unsigned(r) * NT + tid] = q[r];
             }
         }
         if (pf.save_index) {
@@ -218,7 +226,7 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist(P
                 if (tid == 0) a.expect[(size_t(o) * a.n_tsave + pf.save_index) * a.B + b] = e;  // single writer: deterministic
             }
         }
-        __syncthreads();
+        if (!lanes) __syncthreads();
     }
 }
 
@@ -281,6 +289,7 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist_b
     const size_t boff = size_t(b) * a.dim;
     const size_t sv = size_t(a.B) * a.dim;
     const double* __restrict__ coef_b = a.coef + size_t(b) * a.coef_bstride;
+    const bool lanes = LT <= 6 && a.pair.n == 0;  // one amplitude per lane of one wave: lane exchanges instead of the LDS tile
     // the host only takes this path when an interval fits the staging window and the coefficient record fits a stage row
     double2 mu[R], xend[KEEPX ? R : 1], xnext[KEEPX ? R : 1];
     double ud[R], wt[R];
@@ -376,11 +385,13 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist_b
             asm volatile("" : "+v"(tid));  // keep per-lane constants (signs, popcounts, LDS addresses) out of long-lived registers
             const PersistFactor pf = factor_at(fbeg + i);
             const double* cf = scoef[fbeg + i - w0];
-            if (active) {
+            if (!lanes) {
+                if (active) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) tile[unsigned(r) * NT + tid] = v[r];
+                    for (int r = 0; r < R; ++r) tile[unsigned(r) * NT + tid] = v[r];
+                }
+                __syncthreads();
             }
-            __syncthreads();
             double2 q[R];
             if (active) {
 #pragma unroll
@@ -398,7 +409,12 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist_b
                 for (int g = 0; g < kPersistGroups; ++g) {
                     if (g < a.ga) {
                         double2 ts[R], ds[R];
-                        partner_sums<LT, LGT, CPLX>(tile, v, a.amask[g], tid, ts, ds);
+                        if constexpr (LT <= 6) {
+                            if (lanes) partner_sums_lanes<LT, CPLX>(v[0], a.amask[g], tid, ts[0], ds[0]);
+                            else partner_sums<LT, LGT, CPLX>(tile, v, a.amask[g], tid, ts, ds);
+                        } else {
+                            partner_sums<LT, LGT, CPLX>(tile, v, a.amask[g], tid, ts, ds);
+                        }
                         const double cr = cf[g], ci = cf[a.ga + g];
                         const double k1r = pf.br * cr, k1i = pf.bi * cr, k2r = -pf.bi * ci, k2i = pf.br * ci;
 #pragma unroll
@@ -421,7 +437,7 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist_b
                     }
                 }
             }
-            __syncthreads();
+            if (!lanes) __syncthreads();
             if (active) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
@@ -446,10 +462,12 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist_b
                     for (int r = 0; r < R; ++r)
                         v[r] = i == 0 ? (KEEPX ? x0[r] : state_elem(k1 - 1, r)) : park_load(i - 1, unsigned(r) * NT + tid);
                 }
+                if (!lanes) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) tile[unsigned(r) * NT + tid] = mu[r];
+                    for (int r = 0; r < R; ++r) tile[unsigned(r) * NT + tid] = mu[r];
+                }
             }
-            __syncthreads();
+            if (!lanes) __syncthreads();
             if (active) {
                 double2 hm[R];  // H mu
 #pragma unroll
@@ -474,7 +492,12 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist_b
                         const double cr = cf[g], ci = cf[a.ga + g];
                         double z1r = 0.0, z1i = 0.0, z2r = 0.0, z2i = 0.0;
                         double2 ts[R], ds[R];
-                        partner_sums<LT, LGT, true>(tile, mu, a.amask[g], tid, ts, ds);
+                        if constexpr (LT <= 6) {
+                            if (lanes) partner_sums_lanes<LT, true>(mu[0], a.amask[g], tid, ts[0], ds[0]);
+                            else partner_sums<LT, LGT, true>(tile, mu, a.amask[g], tid, ts, ds);
+                        } else {
+                            partner_sums<LT, LGT, true>(tile, mu, a.amask[g], tid, ts, ds);
+                        }
 #pragma unroll
                         for (int r = 0; r < R; ++r) {
                             // (F_g mu) = cr * ts + i * ci * ds
@@ -547,7 +570,7 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist_b
                     }
                 }
             }
-            __syncthreads();  // partner reads of mu (and the reduction scratch) are done
+            if (!lanes || stage_begin) __syncthreads();  // partner reads of mu (and the reduction scratch) are done
         }
         if (KEEPX) {
 #pragma unroll

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -654,6 +655,7 @@ __global__ void k_scatter_grads(ScatterArgs a) {
 
 #include "chain_kernels.hpp"
 #include "persist_kernels.hpp"
+#include "lane_kernels.hpp"
 static_assert(sizeof(PersistFactor) == 48, "plan.hpp sizes the factor table with 48 bytes per entry");
 
 // ---- chained tile passes (chain_kernels.hpp) ------------------------------------------------------------------------
@@ -1415,8 +1417,30 @@ int launch_persist_t(const PersistArgs& pa, int B, hipStream_t stream) {
     return RYDIFF_OK;
 }
 
+template <int LT, bool CPLX>
+int launch_lanes_fwd_t(const PersistArgs& pa, int B, hipStream_t stream) {
+    hipLaunchKernelGGL((k_lanes_fwd<LT, CPLX>), dim3(B), dim3(64), 0, stream, pa);
+    LAUNCH_CHECK();
+    return RYDIFF_OK;
+}
+
+// one amplitude per lane of one wave (lane_kernels.hpp); variant 8 keeps the LDS-tile kernels for A/B tests
+bool lanes_enabled(int N, int ga, int gd, int n_pair) {
+    return g_kernel_variant != 8 && N <= kLaneMaxQubits && n_pair == 0 && ga <= kPersistGroups && gd <= kPersistGroups;
+}
+
 template <bool CPLX>
 int launch_persist(int N, const PersistArgs& pa, int B, hipStream_t stream) {
+    if (lanes_enabled(N, pa.ga, pa.gd, pa.pair.n) && pa.n_factors > 0) {
+        switch (N) {
+            case 1: return launch_lanes_fwd_t<1, CPLX>(pa, B, stream);
+            case 2: return launch_lanes_fwd_t<2, CPLX>(pa, B, stream);
+            case 3: return launch_lanes_fwd_t<3, CPLX>(pa, B, stream);
+            case 4: return launch_lanes_fwd_t<4, CPLX>(pa, B, stream);
+            case 5: return launch_lanes_fwd_t<5, CPLX>(pa, B, stream);
+            default: return launch_lanes_fwd_t<6, CPLX>(pa, B, stream);
+        }
+    }
     switch (N) {
         case 1: return launch_persist_t<1, CPLX>(pa, B, stream);
         case 2: return launch_persist_t<2, CPLX>(pa, B, stream);
@@ -1441,8 +1465,25 @@ int launch_persist_bwd_t(const PersistBwdArgs& pa, int B, hipStream_t stream) {
     return RYDIFF_OK;
 }
 
+template <int LT, bool CPLX>
+int launch_lanes_bwd_t(const PersistBwdArgs& pa, int B, hipStream_t stream) {
+    hipLaunchKernelGGL((k_lanes_bwd<LT, CPLX>), dim3(B), dim3(64), 0, stream, pa);
+    LAUNCH_CHECK();
+    return RYDIFF_OK;
+}
+
 template <bool CPLX>
 int launch_persist_bwd(int N, const PersistBwdArgs& pa, int B, hipStream_t stream) {
+    if (lanes_enabled(N, pa.ga, pa.gd, pa.pair.n) && pa.n_factors > 0) {
+        switch (N) {
+            case 1: return launch_lanes_bwd_t<1, CPLX>(pa, B, stream);
+            case 2: return launch_lanes_bwd_t<2, CPLX>(pa, B, stream);
+            case 3: return launch_lanes_bwd_t<3, CPLX>(pa, B, stream);
+            case 4: return launch_lanes_bwd_t<4, CPLX>(pa, B, stream);
+            case 5: return launch_lanes_bwd_t<5, CPLX>(pa, B, stream);
+            default: return launch_lanes_bwd_t<6, CPLX>(pa, B, stream);
+        }
+    }
     switch (N) {
         case 1: return launch_persist_bwd_t<1, CPLX>(pa, B, stream);
         case 2: return launch_persist_bwd_t<2, CPLX>(pa, B, stream);
@@ -1492,8 +1533,9 @@ int rydiff_set_kernel_variant(int variant) {
     // 0 auto | 1 direct | 2 chained tiles, 512 threads | 3 chained tiles, 256 threads | 4 chained tiles, 1024 threads
     // 5 single-pass LDS tiles with partner-tile loads (forward / recompute passes; adjoint stays direct)
     // 6 chained tiles with sub-tile pipelining (13 <= N <= 22; experimental)
+    // 8 LDS-tile persistent kernels also for N <= 6 (A/B reference of the one-wave lane kernels)
     // 7 auto, but three tile layouts wherever they are legal (21 <= N <= 28; default from N = 23)
-    if (variant < 0 || variant > 7) return fail(RYDIFF_EINVAL, "kernel variant must be 0..7");
+    if (variant < 0 || variant > 8) return fail(RYDIFF_EINVAL, "kernel variant must be 0..8");
     g_force_three_layouts = variant == 7;
     if (variant == 7) variant = 0;
     g_kernel_variant = variant;
@@ -1772,10 +1814,21 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
 
     std::vector<ChainItem> chain;
     std::vector<const double2*> xs;
+    std::vector<ChainItem> part;
     for (int k = persisted ? -1 : pl.T - 1; k >= 0; --k) {
-        build_step_chain(rt, k, chain);
+        // With every factor input on the tape, consecutive intervals whose common save point receives no cotangent run as
+        // ONE chain: the launch that finishes the adjoint of interval k's first factor also starts interval k-1's last one.
+        const int k_hi = k;
+        if (full_tape && chain_enabled(rt)) {
+            while (k > 0 && !((gst || have_gexp) && inject_at[k]) && fprefix[k_hi + 1] - fprefix[k - 1] < (int64_t(1) << 16)) --k;
+        }
+        chain.clear();
+        for (int kk = k; kk <= k_hi; ++kk) {
+            build_step_chain(rt, kk, part);
+            chain.insert(chain.end(), part.begin(), part.end());
+        }
         const int M = int(chain.size());
-        if (M - 1 > pl.chain_slots) return fail(RYDIFF_EWORKSPACE, "internal: chain buffers too small");
+        if (!full_tape && M - 1 > pl.chain_slots) return fail(RYDIFF_EWORKSPACE, "internal: chain buffers too small");
         // recompute the factor inputs x_0 .. x_{M-1}
         xs.assign(M + 1, nullptr);
         xs[0] = state_at(k);
@@ -1796,7 +1849,7 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
                 xs[i] = dst;
             }
         }
-        xs[M] = state_at(k + 1);
+        xs[M] = state_at(k_hi + 1);
         auto dot_h = [&](int stage, const double2* g, const double2* xout) -> int {
             if (!g_tsave) return RYDIFF_OK;
             DotHArgs da{};
