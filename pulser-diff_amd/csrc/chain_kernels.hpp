@@ -180,14 +180,20 @@ __device__ __forceinline__ int dpp_mov(int old, int src) {
     return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xF, BANK, false);
 }
 
+// every destination lane has a valid source lane in these patterns, so the destination needs no initial value
+template <int CTRL, int BANK>
+__device__ __forceinline__ int dpp_mov_all(int src) {
+    return __builtin_amdgcn_mov_dpp(src, CTRL, 0xF, BANK, true);
+}
+
 template <int B>
 __device__ __forceinline__ int lane_xor_i32(int w) {
-    if constexpr (B == 0) return dpp_mov<0xB1, 0xF>(0, w);        // quad_perm [1,0,3,2]
-    else if constexpr (B == 1) return dpp_mov<0x4E, 0xF>(0, w);   // quad_perm [2,3,0,1]
-    else if constexpr (B == 2) {                                   // lanes with bit 2 set take lane-4 (row_ror:4), the others lane+4 (row_ror:12)
-        const int r = dpp_mov<0x124, 0xA>(0, w);
+    if constexpr (B == 0) return dpp_mov_all<0xB1, 0xF>(w);        // quad_perm [1,0,3,2]
+    else if constexpr (B == 1) return dpp_mov_all<0x4E, 0xF>(w);   // quad_perm [2,3,0,1]
+    else if constexpr (B == 2) {                                    // lanes with bit 2 set take lane-4 (row_ror:4), the others lane+4 (row_ror:12)
+        const int r = dpp_mov_all<0x124, 0xA>(w);
         return dpp_mov<0x12C, 0x5>(r, w);
-    } else if constexpr (B == 3) return dpp_mov<0x128, 0xF>(0, w);  // row_ror:8
+    } else if constexpr (B == 3) return dpp_mov_all<0x128, 0xF>(w);  // row_ror:8
     else return __shfl_xor(w, 1 << B, 64);
 }
 
@@ -198,7 +204,7 @@ __device__ __forceinline__ double2 lane_xor(const double2& v) {
     return make_double2(__hiloint2double(a1, a0), __hiloint2double(b1, b0));
 }
 
-template <int LT, bool CPLX>
+template <int LT, bool CPLX, bool FULL = false>
 __device__ __forceinline__ void partner_sums_lanes(const double2& own, uint32_t mask, unsigned tid, double2& ts, double2& ds) {
     static_assert(LT <= 6, "one amplitude per lane");
     ts = make_double2(0.0, 0.0);
@@ -206,7 +212,7 @@ __device__ __forceinline__ void partner_sums_lanes(const double2& own, uint32_t 
     auto bit = [&](auto bc) {
         constexpr int b = decltype(bc)::value;
         if constexpr (b < LT) {
-            if (mask >> b & 1u) {  // wave-uniform
+            if (FULL || (mask >> b & 1u)) {  // wave-uniform
                 const double2 q = lane_xor<b>(own);
                 ts.x += q.x;
                 ts.y += q.y;

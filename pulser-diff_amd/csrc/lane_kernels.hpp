@@ -79,8 +79,11 @@ struct LaneRecLoader {
 // ---------------------------------------------------------------------------------------------------------------------
 // forward: every factor of every time step, one wave per trajectory
 // ---------------------------------------------------------------------------------------------------------------------
-template <int LT, bool CPLX>
+// FAST: one amplitude group that drives every qubit (a global channel) and at most one detuning group — the usual
+// sequence: no group loops, no mask tests, no predicated coefficient broadcasts in the factor loop.
+template <int LT, bool CPLX, bool FAST>
 __global__ __launch_bounds__(64) void k_lanes_fwd(PersistArgs a) {
+    constexpr int GL = FAST ? 1 : kPersistGroups;
     constexpr int NT = 1 << LT;
     const unsigned lane = threadIdx.x;
     const bool active = lane < NT;
@@ -112,17 +115,17 @@ __global__ __launch_bounds__(64) void k_lanes_fwd(PersistArgs a) {
             // diagonal: gamma + beta * (U(x) + sum_g c_det[g] * cnt_g(x))
             double d = ud;
 #pragma unroll
-            for (int g = 0; g < kPersistGroups; ++g)
-                if (g < a.gd) d = fma(bcast_lane(cur.cd[g], fs), cnt[g], d);
+            for (int g = 0; g < GL; ++g)
+                if (FAST || g < a.gd) d = fma(bcast_lane(cur.cd[g], fs), cnt[g], d);
             const double dr = fma(br, d, gr), di = fma(bi, d, gi);
             double2 q;
             q.x = dr * v.x - di * v.y;
             q.y = dr * v.y + di * v.x;
 #pragma unroll
-            for (int g = 0; g < kPersistGroups; ++g) {
-                if (g < a.ga) {
+            for (int g = 0; g < GL; ++g) {
+                if (FAST || g < a.ga) {
                     double2 ts, ds;
-                    partner_sums_lanes<LT, CPLX>(v, a.amask[g], lane, ts, ds);
+                    partner_sums_lanes<LT, CPLX, FAST>(v, a.amask[g], lane, ts, ds);
                     const double cr = bcast_lane(cur.cr[g], fs);
                     const double k1r = br * cr, k1i = bi * cr;
                     q.x += k1r * ts.x - k1i * ts.y;
@@ -158,8 +161,9 @@ __global__ __launch_bounds__(64) void k_lanes_fwd(PersistArgs a) {
 //   Everything the NEXT interval needs from global memory (its start state, the cotangent weights of its end point) is
 //   requested while the current interval computes.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int LT, bool CPLX>
+template <int LT, bool CPLX, bool FAST>
 __global__ __launch_bounds__(64) void k_lanes_bwd(PersistBwdArgs a) {
+    constexpr int GL = FAST ? 1 : kPersistGroups;
     constexpr int NT = 1 << LT;
     __shared__ __attribute__((aligned(16))) double2 park[(kLaneChunk - 1) * 64];
     const unsigned lane = threadIdx.x;
@@ -246,17 +250,17 @@ __global__ __launch_bounds__(64) void k_lanes_bwd(PersistBwdArgs a) {
             const double br = bcast_lane(cur.br, fs), bi = bcast_lane(cur.bi, fs);
             double d = ud;
 #pragma unroll
-            for (int g = 0; g < kPersistGroups; ++g)
-                if (g < a.gd) d = fma(bcast_lane(cur.cd[g], fs), cnt[g], d);
+            for (int g = 0; g < GL; ++g)
+                if (FAST || g < a.gd) d = fma(bcast_lane(cur.cd[g], fs), cnt[g], d);
             const double dr = fma(br, d, gr), di = fma(bi, d, gi);
             double2 q;
             q.x = dr * v.x - di * v.y;
             q.y = dr * v.y + di * v.x;
 #pragma unroll
-            for (int g = 0; g < kPersistGroups; ++g) {
-                if (g < a.ga) {
+            for (int g = 0; g < GL; ++g) {
+                if (FAST || g < a.ga) {
                     double2 ts, ds;
-                    partner_sums_lanes<LT, CPLX>(v, a.amask[g], lane, ts, ds);
+                    partner_sums_lanes<LT, CPLX, FAST>(v, a.amask[g], lane, ts, ds);
                     const double cr = bcast_lane(cur.cr[g], fs);
                     const double k1r = br * cr, k1i = bi * cr;
                     q.x += k1r * ts.x - k1i * ts.y;
@@ -292,20 +296,20 @@ __global__ __launch_bounds__(64) void k_lanes_bwd(PersistBwdArgs a) {
             const double br = bcast_lane(cur.br, fs), bi = bcast_lane(cur.bi, fs);
             double d = ud;
 #pragma unroll
-            for (int g = 0; g < kPersistGroups; ++g)
-                if (g < a.gd) d = fma(bcast_lane(cur.cd[g], fs), cnt[g], d);
+            for (int g = 0; g < GL; ++g)
+                if (FAST || g < a.gd) d = fma(bcast_lane(cur.cd[g], fs), cnt[g], d);
             double2 hm = make_double2(d * mu.x, d * mu.y);  // H mu
             const double pr = br * mu.x + bi * mu.y, pi = bi * mu.x - br * mu.y;
             const double rr = pr * v.x - pi * v.y;  // Re(beta conj(mu) x)
             wt += rr;
 #pragma unroll
-            for (int g = 0; g < kPersistGroups; ++g)
-                if (g < a.gd) acc_det[g] = fma(rr, cnt[g], acc_det[g]);
+            for (int g = 0; g < GL; ++g)
+                if (FAST || g < a.gd) acc_det[g] = fma(rr, cnt[g], acc_det[g]);
 #pragma unroll
-            for (int g = 0; g < kPersistGroups; ++g) {
-                if (g < a.ga) {
+            for (int g = 0; g < GL; ++g) {
+                if (FAST || g < a.ga) {
                     double2 ts, ds;
-                    partner_sums_lanes<LT, true>(mu, a.amask[g], lane, ts, ds);
+                    partner_sums_lanes<LT, true, FAST>(mu, a.amask[g], lane, ts, ds);
                     const double cr = bcast_lane(cur.cr[g], fs), ci = bcast_lane(cur.ci[g], fs);
                     // (F_g mu) = cr * ts + i * ci * ds
                     hm.x += cr * ts.x - ci * ds.y;
@@ -327,8 +331,8 @@ __global__ __launch_bounds__(64) void k_lanes_bwd(PersistBwdArgs a) {
             if (stage_begin) {  // the exponential is complete: reduce its gradient record over the active lanes
                 double* rec = a.ge + size_t(b) * a.ge_bstride + size_t(stage) * a.ge_sstride + size_t(b % kGradReplicas) * (a.NC + 1);
 #pragma unroll
-                for (int g = 0; g < kPersistGroups; ++g) {
-                    if (g < a.ga) {
+                for (int g = 0; g < GL; ++g) {
+                    if (FAST || g < a.ga) {
                         const double s1 = lanes_sum<LT>(acc_re[g]), s2 = lanes_sum<LT>(acc_im[g]);
                         if (lane == 0) {
                             unsafeAtomicAdd(rec + g, s1);

@@ -1419,7 +1419,10 @@ int launch_persist_t(const PersistArgs& pa, int B, hipStream_t stream) {
 
 template <int LT, bool CPLX>
 int launch_lanes_fwd_t(const PersistArgs& pa, int B, hipStream_t stream) {
-    hipLaunchKernelGGL((k_lanes_fwd<LT, CPLX>), dim3(B), dim3(64), 0, stream, pa);
+    if (pa.ga == 1 && pa.gd <= 1 && pa.amask[0] == (1u << LT) - 1u)
+        hipLaunchKernelGGL((k_lanes_fwd<LT, CPLX, true>), dim3(B), dim3(64), 0, stream, pa);
+    else
+        hipLaunchKernelGGL((k_lanes_fwd<LT, CPLX, false>), dim3(B), dim3(64), 0, stream, pa);
     LAUNCH_CHECK();
     return RYDIFF_OK;
 }
@@ -1467,7 +1470,10 @@ int launch_persist_bwd_t(const PersistBwdArgs& pa, int B, hipStream_t stream) {
 
 template <int LT, bool CPLX>
 int launch_lanes_bwd_t(const PersistBwdArgs& pa, int B, hipStream_t stream) {
-    hipLaunchKernelGGL((k_lanes_bwd<LT, CPLX>), dim3(B), dim3(64), 0, stream, pa);
+    if (pa.ga == 1 && pa.gd <= 1 && pa.amask[0] == (1u << LT) - 1u)
+        hipLaunchKernelGGL((k_lanes_bwd<LT, CPLX, true>), dim3(B), dim3(64), 0, stream, pa);
+    else
+        hipLaunchKernelGGL((k_lanes_bwd<LT, CPLX, false>), dim3(B), dim3(64), 0, stream, pa);
     LAUNCH_CHECK();
     return RYDIFF_OK;
 }

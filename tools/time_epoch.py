@@ -15,6 +15,9 @@ import torch
 from pulser_diff_amd import pulses as pl
 from pulser_diff_amd.model import QuantumModel
 from pulser_diff_amd.solver import SolverType
+from pulser_diff_amd import _native
+import os
+_native.set_kernel_variant(int(os.environ.get('RYDIFF_VARIANT', '0')))  # 8: LDS-tile kernels instead of the lane kernels
 
 rows = int(sys.argv[1]) if len(sys.argv) > 2 else 1
 cols = int(sys.argv[2]) if len(sys.argv) > 2 else 2
