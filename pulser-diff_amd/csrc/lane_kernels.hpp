@@ -11,6 +11,8 @@
 //   * the next chunk's records are loaded while the current chunk runs (factor entries at the chunk's start, their
 //     coefficient records half a chunk later, when the stage indices have arrived),
 //   * wave reductions (expectation values, gradient records) are DPP butterflies over the 2^N active lanes only.
+// (The register records pay off for ONE wave only: with 2..16 waves per workgroup every wave repeats the ~20 broadcasts that
+// one staged LDS row serves, and k_persist got slower — N = 12: 2.89 -> 3.27 us per factor — so it keeps its LDS staging.)
 #pragma once
 
 constexpr int kLaneMaxQubits = 6;

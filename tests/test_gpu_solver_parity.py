@@ -177,17 +177,22 @@ def test_twelve_qubit_chain_against_matrix_free_oracle(cuda_device):
 
 
 # ---- persistent single-launch adjoint (N <= 11) ---------------------------------------------------------------------
-@pytest.mark.parametrize("n_qubits,solver_name,batch_tables", [(1, "KRYLOV_SE", 1), (3, "DP5_SE", 1), (6, "KRYLOV_SE", 2),
-                                                              (9, "DP5_SE", 1), (10, "KRYLOV_SE", 1), (11, "KRYLOV_SE", 2)])
-def test_persistent_adjoint_matches_per_factor_launches(cuda_device, n_qubits, solver_name, batch_tables):
-    """A/B on the GPU: the one-launch reverse sweep (k_persist_bwd: 1, 2 and 4 amplitudes per thread, factor inputs
-    parked in LDS or in the global scratch slots, Magnus stages of the continuous solver) against the per-factor
-    launches, which are pinned to the oracle's autograd above.  All five gradients, cotangents on states AND on
-    expectation values at every save point, shared and per-trajectory tables."""
+@pytest.mark.parametrize("n_qubits,solver_name,batch_tables,local,phase,ref_variant", [
+    (1, "KRYLOV_SE", 1, False, True, 1), (3, "DP5_SE", 1, True, True, 1), (6, "KRYLOV_SE", 2, True, True, 1),
+    (9, "DP5_SE", 1, True, True, 1), (10, "KRYLOV_SE", 1, True, True, 1), (11, "KRYLOV_SE", 2, True, True, 1),
+    # one-wave lane kernels (<= 6 qubits): global drive only = the FAST instantiation, real and complex drives, both
+    # solvers; against the per-factor launches (1) and against the LDS-tile persistent kernels they replace (8)
+    (2, "KRYLOV_SE", 1, False, False, 1), (4, "KRYLOV_SE", 2, False, True, 1), (5, "DP5_SE", 1, False, False, 1),
+    (6, "KRYLOV_SE", 1, False, True, 8), (4, "DP5_SE", 1, True, True, 8), (3, "KRYLOV_SE", 2, False, False, 8)])
+def test_persistent_adjoint_matches_per_factor_launches(cuda_device, n_qubits, solver_name, batch_tables, local, phase, ref_variant):
+    """A/B on the GPU: the one-launch sweeps (k_lanes_fwd / k_lanes_bwd up to 6 qubits; k_persist / k_persist_bwd: 1, 2
+    and 4 amplitudes per thread, factor inputs parked in LDS or in the global scratch slots; Magnus stages of the
+    continuous solver) against the per-factor launches, which are pinned to the oracle's autograd above.  All five
+    gradients, cotangents on states AND on expectation values at every save point, shared and per-trajectory tables."""
     from pulser_diff_amd import _native
     from pulser_diff_amd.solver import SolverType, evolve
 
-    terms = random_terms(n_qubits, 33, 0.004, seed=300 + n_qubits, local=n_qubits > 1)
+    terms = random_terms(n_qubits, 33, 0.004, seed=300 + n_qubits, local=local and n_qubits > 1, phase=phase)
     tsave0 = torch.cat([torch.zeros(1, dtype=torch.float64), torch.linspace(0.011, 0.12, 6, dtype=torch.float64)])
     gen = torch.Generator().manual_seed(n_qubits)
     psi = torch.randn(2, 2**n_qubits, generator=gen, dtype=torch.complex128)
@@ -195,7 +200,7 @@ def test_persistent_adjoint_matches_per_factor_launches(cuda_device, n_qubits, s
     obs = torch.stack([R.total_magnetization_diag(n_qubits), torch.rand(2**n_qubits, generator=gen, dtype=torch.float64)]).to(cuda_device)
     probe = torch.randn(2**n_qubits, generator=gen, dtype=torch.complex128).to(cuda_device)
     out = {}
-    for variant in (1, 0):
+    for variant in (ref_variant, 0):
         _native.set_kernel_variant(variant)
         try:
             amp, det, u, spec = to_native(terms, cuda_device, getattr(SolverType, solver_name), batch_tables=batch_tables)
@@ -211,7 +216,7 @@ def test_persistent_adjoint_matches_per_factor_launches(cuda_device, n_qubits, s
                                                      for t in leaves]  # a single qubit has no pair interactions
         finally:
             _native.set_kernel_variant(0)
-    for name, ref, got in zip(("expect", "amp", "det", "u", "tsave", "psi0"), out[1], out[0]):
+    for name, ref, got in zip(("expect", "amp", "det", "u", "tsave", "psi0"), out[ref_variant], out[0]):
         if ref.numel():
             assert rel_err(got.numpy(), ref.numpy()) < 1e-10, name
 
