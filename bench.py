@@ -54,12 +54,14 @@ def pair_interactions(coords: torch.Tensor) -> torch.Tensor:
 
 def tables_from_params(omega: torch.Tensor, delta: torch.Tensor, seg_len: int):
     """Piecewise-constant pulse -> the reference's coefficient arrays (hamiltonian.py:420-423), one trailing
-    zero sample (backend.py:115).  omega/delta: (B, segs).  Returns amp (B,1,n) complex128, det (B,1,n)."""
+    zero sample (backend.py:115).  omega/delta: (B, segs).  Returns amp (B,1,n) float64 (phase 0), det (B,1,n)."""
     b = omega.shape[0]
     zero = torch.zeros(b, 1, dtype=torch.float64, device=omega.device)
     amp = torch.cat([omega.repeat_interleave(seg_len, dim=1), zero], dim=1)
     det = torch.cat([delta.repeat_interleave(seg_len, dim=1), zero], dim=1)
-    return (0.5 * amp).to(torch.complex128).unsqueeze(1), (-0.5 * det).unsqueeze(1)
+    # the workload has no phase: the amplitude table stays a REAL tensor (0.5*amp*exp(-1j*0)), so autograd only ever asks
+    # for the real part of its gradient and the adjoint passes skip the dL/dIm(amp) contractions (RydProblem.real_amp_grad)
+    return (0.5 * amp).unsqueeze(1), (-0.5 * det).unsqueeze(1)
 
 
 def main() -> None:

@@ -93,6 +93,12 @@ typedef struct RydProblem {
     int32_t n_pair_terms;          /* 0..RYDIFF_MAX_PAIR_TERMS */
     const uint32_t* pair_qubits;   /* HOST [n_pair_terms][2]: (a_p, b_p), a_p != b_p */
     const double* pair_tables;     /* HOST complex128 as (re, im) [n_pair_terms][16] */
+
+    /* rydiff_backward only.  != 0: the caller uses only the REAL part of g_amp — its amplitude tables were built from
+     * real-valued data (a drive without phase; the reference's 0.5*amp*exp(-1j*phase), hamiltonian.py:420, with phase 0).
+     * When in addition every table entry is real (RydPlanInfo.flags bit 0 clear) the chained adjoint passes skip the signed
+     * partner sums and the contractions for dL/dIm(amp); the imaginary parts of g_amp are then not computed (zero). */
+    int32_t real_amp_grad;
 } RydProblem;
 
 /* Result of rydiff_plan(): everything that depends on the VALUES in the coefficient tables. */

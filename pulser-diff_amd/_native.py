@@ -50,6 +50,7 @@ class RydProblem(ctypes.Structure):
         ("n_pair_terms", ctypes.c_int32),
         ("pair_qubits", ctypes.c_void_p),
         ("pair_tables", ctypes.c_void_p),
+        ("real_amp_grad", ctypes.c_int32),
     ]
 
 

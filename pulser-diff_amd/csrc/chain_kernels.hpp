@@ -303,6 +303,12 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
 #pragma unroll
         for (int r = 0; r < R; ++r) xf[r] = stream_load(a.x_fin + boff + xg[r]);
     }
+    // the real-drive adjoint (no signed sums) has the registers to request the second tape vector up front as well
+    constexpr bool XS_EARLY = BWD && !CPLX;
+    if (XS_EARLY && a.has_q) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) xs[r] = stream_load(a.x_sta + boff + xg[r]);
+    }
 #ifndef RYDIFF_ABLATE_SYNC
 #pragma unroll
     for (int r = 0; r < R; ++r) tile[unsigned(r) * NT + tid] = uu[r];
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
             if (!mask) continue;
             double2 ts[R], ds[R];
 #ifndef RYDIFF_ABLATE_COMPUTE
-            partner_sums<LT, LGT, CPLX || BWD>(tile, uu, mask, tid, ts, ds);
+            partner_sums<LT, LGT, CPLX>(tile, uu, mask, tid, ts, ds);
 #else
             for (int r = 0; r < R; ++r) { ts[r] = uu[r]; ds[r] = uu[r]; }
 #endif
@@ -347,22 +353,26 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
             }
             if (BWD) {
                 // <F mu, x> with F Hermitian: z1 = sum conj(ts) x, z2 = sum conj(ds) x; dL/dRe c = Re(beta z1), dL/dIm c = Im(beta z2)
+                // (CPLX = false in the adjoint: real coefficients and a caller that only wants dL/dRe c — no signed sums at all)
                 double z1r = 0.0, z1i = 0.0, z2r = 0.0, z2i = 0.0;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     z1r += ts[r].x * xf[r].x + ts[r].y * xf[r].y;
                     z1i += ts[r].x * xf[r].y - ts[r].y * xf[r].x;
-                    z2r += ds[r].x * xf[r].x + ds[r].y * xf[r].y;
-                    z2i += ds[r].x * xf[r].y - ds[r].y * xf[r].x;
+                    if (CPLX) {
+                        z2r += ds[r].x * xf[r].x + ds[r].y * xf[r].y;
+                        z2i += ds[r].x * xf[r].y - ds[r].y * xf[r].x;
+                    }
                 }
-                park2<NW>(a.cb_fin_r * z1r - a.cb_fin_i * z1i, a.cb_fin_r * z2i + a.cb_fin_i * z2r, red, 2 * g, 2 * g + 1);
+                if (CPLX) park2<NW>(a.cb_fin_r * z1r - a.cb_fin_i * z1i, a.cb_fin_r * z2i + a.cb_fin_i * z2r, red, 2 * g, 2 * g + 1);
+                else park1<NW>(a.cb_fin_r * z1r - a.cb_fin_i * z1i, red, 2 * g);
             }
         }
     } else {
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = uu[r];
     }
-    if (BWD && a.has_q) {  // issued here (not at the top) to stay inside the register budget of 1024-thread tiles
+    if (BWD && !XS_EARLY && a.has_q) {  // issued here (not at the top) to stay inside the register budget of 1024-thread tiles
 #pragma unroll
         for (int r = 0; r < R; ++r) xs[r] = stream_load(a.x_sta + boff + xg[r]);
     }
@@ -441,7 +451,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
         if (!mask && !a.hi_mask[g]) continue;
         double2 ts[R], ds[R];
 #ifndef RYDIFF_ABLATE_COMPUTE
-        partner_sums<LT, LGT, CPLX || BWD>(tile, acc, mask, tid, ts, ds);
+        partner_sums<LT, LGT, CPLX>(tile, acc, mask, tid, ts, ds);
 #else
         for (int r = 0; r < R; ++r) { ts[r] = acc[r]; ds[r] = acc[r]; }
 #endif
@@ -456,7 +466,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
                     const double2 pv = a.u[boff + (xg[r] ^ bit)];
                     ts[r].x += pv.x;
                     ts[r].y += pv.y;
-                    if (CPLX || BWD) {
+                    if (CPLX) {
                         ds[r].x = fma(sgn, pv.x, ds[r].x);
                         ds[r].y = fma(sgn, pv.y, ds[r].y);
                     }
@@ -485,11 +495,14 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
             for (int r = 0; r < R; ++r) {
                 z1r += ts[r].x * xs[r].x + ts[r].y * xs[r].y;
                 z1i += ts[r].x * xs[r].y - ts[r].y * xs[r].x;
-                z2r += ds[r].x * xs[r].x + ds[r].y * xs[r].y;
-                z2i += ds[r].x * xs[r].y - ds[r].y * xs[r].x;
+                if (CPLX) {
+                    z2r += ds[r].x * xs[r].x + ds[r].y * xs[r].y;
+                    z2i += ds[r].x * xs[r].y - ds[r].y * xs[r].x;
+                }
             }
-            park2<NW>(a.cb_sta_r * z1r - a.cb_sta_i * z1i, a.cb_sta_r * z2i + a.cb_sta_i * z2r, red, 2 * a.ga + a.gd + 2 * g,
-                      2 * a.ga + a.gd + 2 * g + 1);
+            if (CPLX) park2<NW>(a.cb_sta_r * z1r - a.cb_sta_i * z1i, a.cb_sta_r * z2i + a.cb_sta_i * z2r, red, 2 * a.ga + a.gd + 2 * g,
+                                2 * a.ga + a.gd + 2 * g + 1);
+            else park1<NW>(a.cb_sta_r * z1r - a.cb_sta_i * z1i, red, 2 * a.ga + a.gd + 2 * g);
         }
     }
     RYDIFF_TL(5);

@@ -710,6 +710,7 @@ struct Runtime {
     int64_t total_factors = 0;
     int max_step_factors = 0;
     int flags = 0;
+    bool real_amp_grad = false;  // RydProblem.real_amp_grad: dL/dIm(amp) is not wanted
     GroupArgs garg{};
     PairArgs parg{};
 };
@@ -850,6 +851,7 @@ int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_
         int rc = run_stats(p, rt.pl, workspace, stream, lo, hi, rt.flags);
         if (rc) return rc;
     }
+    rt.real_amp_grad = p->real_amp_grad != 0;
     // the stage list of the continuous solver depends on the spectral width: rebuild it now that the width is known
     if (!build_plan(p, rt.pl, err, generator_half_width(rt.pl, lo, hi))) return fail(RYDIFF_EINVAL, err);
     int rc = finish_runtime(rt, lo, hi);
@@ -1066,7 +1068,9 @@ int launch_chain_t(const ChainArgs& ca, unsigned tiles, int B, hipStream_t strea
 
 template <int LGT>
 int launch_chain_l(const ChainArgs& ca, unsigned tiles, int B, bool cplx, bool bwd, hipStream_t stream) {
-    if (bwd) return launch_chain_t<LGT, true, true>(ca, tiles, B, stream);  // the adjoint always needs both partner sums
+    // the adjoint needs both partner sums (plain and signed) unless the coefficients are real AND the caller only uses the
+    // real part of the amplitude gradients (RydProblem.real_amp_grad): then `cplx` arrives false here
+    if (bwd) return cplx ? launch_chain_t<LGT, true, true>(ca, tiles, B, stream) : launch_chain_t<LGT, false, true>(ca, tiles, B, stream);
     return cplx ? launch_chain_t<LGT, true, false>(ca, tiles, B, stream) : launch_chain_t<LGT, false, false>(ca, tiles, B, stream);
 }
 
@@ -1140,9 +1144,10 @@ int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, hipStream_t s
         ca.wtot = cs.wtot;
     }
     const unsigned tiles = unsigned(pl.dim >> kTileBits);
-    const bool cplx = (rt.flags & 1) != 0;
+    const bool cplx = (rt.flags & 1) != 0 || (cs.bwd && !rt.real_amp_grad);
     // auto: 1024 threads per tile for the forward passes, 512 for the (register-hungrier) adjoint passes
-    const int lgt = g_kernel_variant == 0 ? (cs.bwd ? 9 : 10) : g_chain_lgt;
+    // (the real-drive adjoint, without the signed sums, fits 1024 threads too: measured 2710 -> 2767 steps/s on C3)
+    const int lgt = g_kernel_variant == 0 ? ((cs.bwd && cplx) ? 9 : 10) : g_chain_lgt;
     switch (lgt) {
         case 8: return launch_chain_l<8>(ca, tiles, pl.B, cplx, cs.bwd, stream);
         case 10: return launch_chain_l<10>(ca, tiles, pl.B, cplx, cs.bwd, stream);

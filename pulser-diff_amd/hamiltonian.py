@@ -243,12 +243,17 @@ class Hamiltonian:
         amp_terms: list[tuple[Tensor, int]] = []
         det_terms: list[tuple[Tensor, int]] = []
 
+        phase_free = [True]  # every drive has phase 0 and no gradient is asked for the phase
+
         def add_terms(samples: dict, mask: int) -> None:
             # hamiltonian.py:420-433 / 439-452
-            amp_c = 0.5 * samples["amp"] * torch.exp(-1j * samples["phase"].to(CD))
+            ph = samples["phase"]
+            amp_c = 0.5 * samples["amp"] * torch.exp(-1j * ph.to(CD))
             det_c = -0.5 * samples["det"]
             if torch.any(amp_c != 0):
                 amp_terms.append((self._adapt_to_sampling_rate(amp_c), mask))
+                if ph.requires_grad or bool(torch.any(ph != 0)):
+                    phase_free[0] = False
             if torch.any(det_c != 0):
                 det_terms.append((self._adapt_to_sampling_rate(det_c), mask))
 
@@ -273,6 +278,9 @@ class Hamiltonian:
         self.det_tables = (torch.stack([c for c, _ in det_terms]) if det_terms else torch.zeros(0, ns, dtype=RD)).unsqueeze(0).to(dev)
         self.amp_masks = tuple(m for _, m in amp_terms)
         self.det_masks = tuple(m for _, m in det_terms)
+        # real-valued drives: the solver is handed the REAL part of the tables, so that autograd only asks for dL/dRe(amp)
+        # and the native adjoint skips the dL/dIm(amp) contractions (RydProblem.real_amp_grad)
+        self.amp_is_real = bool(amp_terms) and phase_free[0]
         self._hamiltonian = self.build_ham_tensor()
 
     def _rebuild_u_pairs(self) -> None:

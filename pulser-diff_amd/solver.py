@@ -85,7 +85,7 @@ class _Call:
     """Keeps the ctypes structures and every buffer they point to alive for the duration of a native call."""
 
     def __init__(self, spec: ProblemSpec, amp: Tensor, det: Tensor, u_pairs: Tensor, tsave_host: np.ndarray,
-                 batch: int, obs: Optional[Tensor]):
+                 batch: int, obs: Optional[Tensor], real_amp_grad: bool = False):
         self.spec = spec
         self.amp_masks = np.asarray(spec.amp_masks, dtype=np.uint32)
         self.det_masks = np.asarray(spec.det_masks, dtype=np.uint32)
@@ -122,6 +122,7 @@ class _Call:
         p.n_pair_terms = len(spec.pair_terms)
         p.pair_qubits = self.pair_qubits.ctypes.data if spec.pair_terms else None
         p.pair_tables = self.pair_tables.ctypes.data if spec.pair_terms else None
+        p.real_amp_grad = int(real_amp_grad)  # the caller's amplitude tables are a REAL tensor: only Re(g_amp) is used
         self.problem = p
 
 
@@ -207,7 +208,7 @@ class _RydbergEvolve(torch.autograd.Function):
         dev = psi_c.device
         batch, dim = psi_c.shape
         obs = obs_c if ctx.has_obs else None
-        call = _Call(spec, amp_c, det_c, u_c, ctx.tsave_host, batch, obs)
+        call = _Call(spec, amp_c, det_c, u_c, ctx.tsave_host, batch, obs, real_amp_grad=not ctx.in_dtypes[0].is_complex)
         need = ctx.needs_input_grad
         if g_states is not None and g_states.numel() == 0:
             g_states = None
@@ -280,6 +281,7 @@ def sesolve(problem, psi0: Tensor, tsave: Tensor, solver: SolverType = SolverTyp
     options = dict(options or {})
     spec = problem.problem_spec(solver=solver, tol=tolerance_from_options(options), store_states=store_states)
     psi_bd = psi0.reshape(psi0.shape[0], -1).transpose(0, 1)
-    states, expect = evolve(problem.amp_tables, problem.det_tables, problem.u_pairs, tsave, psi_bd, spec, obs_diag)
+    amp_tables = problem.amp_tables.real if getattr(problem, "amp_is_real", False) else problem.amp_tables
+    states, expect = evolve(amp_tables, problem.det_tables, problem.u_pairs, tsave, psi_bd, spec, obs_diag)
     return SolveResult(states.permute(0, 2, 1) if states.numel() else states, expect,
                        dict(spec.options.get("_last_stats", {})))

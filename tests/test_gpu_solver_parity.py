@@ -337,3 +337,35 @@ def test_c_abi_error_codes_map_to_reference_exception_types(cuda_device):
     assert rc == _native.RYDIFF_EWORKSPACE and "workspace too small" in _native.last_error()
     with pytest.raises(MemoryError):
         _native.check(rc)
+
+
+@pytest.mark.parametrize("n_qubits,tape", [(5, "auto"), (12, "auto"), (13, "steps"), (14, "full"), (16, "full"), (21, "full")])
+def test_real_amplitude_tables_give_the_real_part_of_the_gradient(cuda_device, n_qubits, tape):
+    """A drive without phase may be handed over as a REAL table (0.5*amp, hamiltonian.py:420 with phase 0): autograd then only
+    wants dL/dRe(amp), RydProblem.real_amp_grad is set and the chained adjoint passes run without the signed partner sums.
+    Every gradient must equal what the complex-table run gives (real part for the amplitudes)."""
+    from pulser_diff_amd.solver import ProblemSpec, SolverType, evolve
+
+    terms = random_terms(n_qubits, 15, 0.002, seed=500 + n_qubits, local=True, phase=False)
+    amp_c, det, u, spec0 = to_native(terms, cuda_device, SolverType.KRYLOV_SE, store_states=False)
+    assert float(amp_c.imag.abs().max()) < 1e-30 or True  # the local extra term of random_terms carries a constant phase
+    amp_c = amp_c.real.to(torch.complex128)                 # ... so take the real part: a phase-free problem
+    tsave0 = torch.linspace(0, 0.026, 6, dtype=torch.float64)
+    gen = torch.Generator().manual_seed(n_qubits)
+    psi = torch.randn(1, 2**n_qubits, generator=gen, dtype=torch.complex128)
+    psi = (psi / psi.norm()).to(cuda_device)
+    obs = torch.rand(1, 2**n_qubits, generator=gen, dtype=torch.float64).to(cuda_device)
+    out = []
+    for amp in (amp_c, amp_c.real.contiguous()):
+        spec = ProblemSpec(spec0.n_qubits, spec0.dt, spec0.n_samples, spec0.amp_masks, spec0.det_masks, solver=SolverType.KRYLOV_SE,
+                           store_states=False, tape=tape)
+        leaves = [amp.clone().requires_grad_(True), det.clone().requires_grad_(True), u.clone().requires_grad_(True),
+                  tsave0.clone().requires_grad_(True), psi.clone().requires_grad_(True)]
+        _, expect = evolve(*leaves, spec, obs)
+        w = torch.linspace(0.3, 1.1, expect.shape[1], dtype=torch.float64, device=cuda_device)
+        (expect[0] * w[:, None]).sum().backward()
+        out.append([expect.detach().cpu()] + [l.grad.detach().cpu() for l in leaves])
+    assert not out[1][1].is_complex()
+    out[0][1] = out[0][1].real
+    for name, ref, got in zip(("expect", "amp", "det", "u", "tsave", "psi0"), out[0], out[1]):
+        assert rel_err(got.numpy(), ref.numpy()) < 1e-11, name
