@@ -47,6 +47,9 @@ for case in range(n_cases):
     psi = (psi / psi.norm(dim=1, keepdim=True)).to(dev)
     obs = torch.rand(1, 2**n, dtype=torch.float64, generator=torch.Generator().manual_seed(case + 1)).to(dev)
     store = bool(rng.integers(0, 2))
+    real_tables = (not cplx) and bool(rng.integers(0, 2))  # phase-free drive handed over as a REAL tensor (RydProblem.real_amp_grad)
+    if real_tables:
+        amp = amp.real.contiguous()
     tape = str(rng.choice(["auto", "steps", "full"]))
     out = {}
     for variant in (1, 0):
@@ -71,7 +74,7 @@ for case in range(n_cases):
     worst = max(worst, e)
     flag = "" if e < 1e-9 else "   <<<<<< MISMATCH"
     fails += e >= 1e-9
-    print(f"case {case:3d}: N={n:2d} B={batch} Bc={bc} {solver.name:9s} Ka={ka} Kd={kd} cplx={int(cplx)} store={int(store)} tape={out[(0, 'stats')]['tape']:5s} "
+    print(f"case {case:3d}: N={n:2d} B={batch} Bc={bc} {solver.name:9s} Ka={ka} Kd={kd} cplx={int(cplx)} real={int(real_tables)} store={int(store)} tape={out[(0, 'stats')]['tape']:5s} "
           f"stages={out[(0, 'stats')]['n_stages']:3d} max rel err {e:.1e}{flag}", flush=True)
 print(f"worst {worst:.2e}; {fails} mismatches out of {n_cases}")
 sys.exit(1 if fails else 0)
