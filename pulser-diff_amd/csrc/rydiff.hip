@@ -711,6 +711,7 @@ struct Runtime {
     int max_step_factors = 0;
     int flags = 0;
     bool real_amp_grad = false;  // RydProblem.real_amp_grad: dL/dIm(amp) is not wanted
+    bool prefer_direct = false;  // few tiles in flight: one-amplitude-per-thread kernels instead of the chained tile passes
     GroupArgs garg{};
     PairArgs parg{};
 };
@@ -830,9 +831,19 @@ void fill_info(const Runtime& rt, double lo, double hi, size_t ws, RydPlanInfo* 
     info->workspace_bytes = ws;
 }
 
+// A tile pass keeps one CU busy for ~10 us per tile whatever the register size, so with few tiles in flight (one 13..18-qubit
+// trajectory: 2..64 tiles on 256 CUs) the one-amplitude-per-thread kernels, which spread over the whole chip, are faster.
+// Measured crossover (tools/time_small.py, bench.py --workload c4 --batch b, variants 0 / 1): forward-only runs up to 2^18
+// amplitudes in flight (N=13: 5.3 vs 9.4 us per pass, N=16 B=4: +13 %), runs with gradients up to 2^17 (N=13: 52 vs 104 ms,
+// N=16 B=2: +5 %; at 2^18 the full tape already wins for a batch).  Explicit kernel variants are left alone (A/B tests).
+bool few_tiles(const Plan& pl, bool with_gradients) {
+    if (g_kernel_variant != 0 || g_force_three_layouts) return false;
+    return (size_t(pl.B) << pl.N) <= (size_t(1) << (with_gradients ? 17 : 18));
+}
+
 // the full per-factor tape exists only where the chained tile passes run
 bool full_tape_possible(const Plan& pl) {
-    return pl.N > kTileBitsHost && pl.N <= 28 && pl.n_pair == 0 && g_kernel_variant != 1 && g_kernel_variant != 5;
+    return pl.N > kTileBitsHost && pl.N <= 28 && pl.n_pair == 0 && g_kernel_variant != 1 && g_kernel_variant != 5 && !few_tiles(pl, true);
 }
 
 // common prologue of forward / backward: plan, (optional) stats, carve, upload metadata, expand coefficients, udiag
@@ -858,6 +869,7 @@ int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_
     if (rc) return rc;
     Plan& pl = rt.pl;
     if (need_tape == 2 && !full_tape_possible(pl)) need_tape = 1;  // full tape only with chained passes
+    rt.prefer_direct = few_tiles(pl, need_backward || need_tape != 0);
     const size_t need = carve(pl, need_tape, need_backward, std::max(rt.max_step_factors - 1, 1), rt.total_factors);
     if (workspace_bytes < need)
         return fail(RYDIFF_EWORKSPACE, "workspace too small: need " + std::to_string(need) + " bytes, got " + std::to_string(workspace_bytes));
@@ -1021,7 +1033,7 @@ uint32_t to_tile_mask(const LayoutDesc& d, uint32_t index_mask) {
 bool chain_enabled(const Runtime& rt) {
     const int N = rt.pl.N;
     if (g_kernel_variant == 1 || g_kernel_variant == 5 || rt.pl.n_pair) return false;  // pair terms: direct kernels
-    return N > kTileBits && N <= 28;
+    return N > kTileBits && N <= 28 && !rt.prefer_direct;
 }
 
 struct ChainStep {

@@ -291,16 +291,23 @@ def test_full_tape_and_step_tape_give_identical_gradients(cuda_device):
     tsave = torch.linspace(0, 0.022, 6, dtype=torch.float64)
     psi0 = R.all_ground_state(n).T.contiguous().to(cuda_device)
     obs = R.total_magnetization_diag(n)[None].to(cuda_device)
+    from pulser_diff_amd import _native
+
     results = {}
-    for mode in ("steps", "full"):
-        amp, det, u, spec = to_native(terms, cuda_device, SolverType.KRYLOV_SE, store_states=False)
-        spec.tape = mode
-        for t in (amp, det, u):
-            t.requires_grad_(True)
-        states, expect = evolve(amp, det, u, tsave, psi0, spec, obs)
-        assert states.numel() == 0
-        (expect[0, -1, 0] + 0.5 * expect[0, 2, 0]).backward()
-        results[mode] = (expect.detach().clone(), amp.grad.clone(), det.grad.clone(), u.grad.clone())
+    _native.set_kernel_variant(2)  # chained tiles forced: one 14-qubit trajectory alone would be routed to the direct kernels
+    try:
+        for mode in ("steps", "full"):
+            amp, det, u, spec = to_native(terms, cuda_device, SolverType.KRYLOV_SE, store_states=False)
+            spec.tape = mode
+            for t in (amp, det, u):
+                t.requires_grad_(True)
+            states, expect = evolve(amp, det, u, tsave, psi0, spec, obs)
+            assert states.numel() == 0
+            assert spec.options["_last_stats"]["tape"] == mode
+            (expect[0, -1, 0] + 0.5 * expect[0, 2, 0]).backward()
+            results[mode] = (expect.detach().clone(), amp.grad.clone(), det.grad.clone(), u.grad.clone())
+    finally:
+        _native.set_kernel_variant(0)
     for a, b in zip(results["steps"], results["full"]):
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-11
 
@@ -355,16 +362,24 @@ def test_real_amplitude_tables_give_the_real_part_of_the_gradient(cuda_device, n
     psi = torch.randn(1, 2**n_qubits, generator=gen, dtype=torch.complex128)
     psi = (psi / psi.norm()).to(cuda_device)
     obs = torch.rand(1, 2**n_qubits, generator=gen, dtype=torch.float64).to(cuda_device)
+    from pulser_diff_amd import _native
+
     out = []
-    for amp in (amp_c, amp_c.real.contiguous()):
-        spec = ProblemSpec(spec0.n_qubits, spec0.dt, spec0.n_samples, spec0.amp_masks, spec0.det_masks, solver=SolverType.KRYLOV_SE,
-                           store_states=False, tape=tape)
-        leaves = [amp.clone().requires_grad_(True), det.clone().requires_grad_(True), u.clone().requires_grad_(True),
-                  tsave0.clone().requires_grad_(True), psi.clone().requires_grad_(True)]
-        _, expect = evolve(*leaves, spec, obs)
-        w = torch.linspace(0.3, 1.1, expect.shape[1], dtype=torch.float64, device=cuda_device)
-        (expect[0] * w[:, None]).sum().backward()
-        out.append([expect.detach().cpu()] + [l.grad.detach().cpu() for l in leaves])
+    # complex tables on the automatically selected kernels; real tables on the chained tiles (forced from 13 qubits on, 1024-
+    # and 512-thread tiles alternately: a single small trajectory would otherwise be routed to the direct kernels)
+    for amp, variant in ((amp_c, 0), (amp_c.real.contiguous(), 0 if n_qubits <= 12 else (4 if n_qubits % 2 else 2))):
+        _native.set_kernel_variant(variant)
+        try:
+            spec = ProblemSpec(spec0.n_qubits, spec0.dt, spec0.n_samples, spec0.amp_masks, spec0.det_masks, solver=SolverType.KRYLOV_SE,
+                               store_states=False, tape=tape)
+            leaves = [amp.clone().requires_grad_(True), det.clone().requires_grad_(True), u.clone().requires_grad_(True),
+                      tsave0.clone().requires_grad_(True), psi.clone().requires_grad_(True)]
+            _, expect = evolve(*leaves, spec, obs)
+            w = torch.linspace(0.3, 1.1, expect.shape[1], dtype=torch.float64, device=cuda_device)
+            (expect[0] * w[:, None]).sum().backward()
+            out.append([expect.detach().cpu()] + [l.grad.detach().cpu() for l in leaves])
+        finally:
+            _native.set_kernel_variant(0)
     assert not out[1][1].is_complex()
     out[0][1] = out[0][1].real
     for name, ref, got in zip(("expect", "amp", "det", "u", "tsave", "psi0"), out[0], out[1]):

@@ -52,7 +52,8 @@ for case in range(n_cases):
         amp = amp.real.contiguous()
     tape = str(rng.choice(["auto", "steps", "full"]))
     out = {}
-    for variant in (1, 0):
+    variants = (1, 0) + ((int(rng.choice([2, 4])),) if n >= 13 else ())  # from 13 qubits also the chained tiles FORCED: auto routes small single trajectories to the direct kernels
+    for variant in variants:
         _native.set_kernel_variant(variant)
         spec = ProblemSpec(n, dt, ns, am, dm, solver=solver, store_states=store, tape=tape)
         leaves = [amp.clone().requires_grad_(True), det.clone().requires_grad_(True), u.clone().requires_grad_(True),
@@ -67,9 +68,10 @@ for case in range(n_cases):
         out[(variant, "stats")] = dict(spec.options["_last_stats"])
     _native.set_kernel_variant(0)
     errs = []
-    for a, b in zip(out[0], out[1]):
-        if b.size:
-            errs.append(float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-3)))  # gradients that are exactly zero (diagonal H) are compared absolutely
+    for variant in variants[1:]:
+        for a, b in zip(out[variant], out[1]):
+            if b.size:
+                errs.append(float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-3)))  # gradients that are exactly zero (diagonal H) are compared absolutely
     e = max(errs)
     worst = max(worst, e)
     flag = "" if e < 1e-9 else "   <<<<<< MISMATCH"
