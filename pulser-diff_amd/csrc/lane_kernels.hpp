@@ -6,7 +6,7 @@
 // for the tile (write, barrier, partner reads) and, worse, one serialised LDS read + wait per scalar of the factor record.
 // Here nothing in the per-factor loop touches memory:
 //   * partners come through DPP lane exchanges (quad permutes / row rotates; ds_bpermute only for bits 4, 5),
-//   * lane t of the wave holds the pre-multiplied scalars of factor f0 + t of the current chunk of 64 factors in its own
+//   * lane t of the wave holds the scalars (gamma, beta, coefficient record) of factor f0 + t of the current chunk of 64 factors in its own
 //     registers and the loop broadcasts them with v_readlane (scalar registers, no wait counters),
 //   * the next chunk's records are loaded while the current chunk runs (factor entries at the chunk's start, their
 //     coefficient records half a chunk later, when the stage indices have arrived),
