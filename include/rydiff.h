@@ -111,6 +111,8 @@ typedef struct RydPlanInfo {
     int32_t flags;                   /* bit 0: some flip coefficient has a non-zero imaginary part */
     int64_t total_factors;           /* factor passes of one forward run = H applications per trajectory */
     size_t workspace_bytes;          /* device workspace needed by forward/backward for the flags given to rydiff_plan */
+    int32_t tape_mode;               /* the tape the workspace was sized for: 0 none, 1 one state per tsave, 2 full (need_tape = 2
+                                        is granted only where the chained tile passes will run) */
 } RydPlanInfo;
 
 #define RYDIFF_PLAN_SCRATCH_BYTES 1024

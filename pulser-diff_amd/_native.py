@@ -65,6 +65,7 @@ class RydPlanInfo(ctypes.Structure):
         ("flags", ctypes.c_int32),
         ("total_factors", ctypes.c_int64),
         ("workspace_bytes", ctypes.c_size_t),
+        ("tape_mode", ctypes.c_int32),
     ]
 
 

@@ -242,9 +242,6 @@ __global__ __launch_bounds__(64) void k_lanes_bwd(PersistBwdArgs a) {
             mu.y += inj.gs.y + w * xend.y;
         }
         const double2 x0 = xnext;
-        // requests for the next interval (one earlier): its start state and the cotangent terms of its end point tsave[k1-1]
-        if (k1 >= 2) xnext = state_at(k1 - 2);
-        inj = inject_terms(k1 - 1);
 
         // one forward factor on a register-resident vector
         auto apply_forward = [&](const double2& v, int fs) -> double2 {
@@ -285,6 +282,12 @@ __global__ __launch_bounds__(64) void k_lanes_bwd(PersistBwdArgs a) {
                 park[i * 64 + lane] = v;
             }
         }
+        // requests for the next interval (one earlier): its start state and the cotangent terms of its end point tsave[k1-1].
+        // Issued HERE, after the last use of a loaded value in this interval (x0 in the recompute loop): the wait counter is
+        // in order and the compiler waits for everything outstanding, so a request issued before that use would be waited for
+        // at once; from here it has the whole adjoint loop to land.
+        if (k1 >= 2) xnext = state_at(k1 - 2);
+        inj = inject_terms(k1 - 1);
         // ---- adjoint of the interval's factors, last to first
         double2 xin = M > 1 ? park[(M - 2) * 64 + lane] : x0;  // input of factor M-1
         for (int i = M - 1; i >= 0; --i) {

@@ -1599,6 +1599,7 @@ int rydiff_plan(const RydProblem* p, int need_tape, int need_backward, void* scr
     if (tm == 2 && !full_tape_possible(rt.pl)) tm = 1;
     const size_t ws = carve(rt.pl, tm, need_backward != 0, std::max(rt.max_step_factors - 1, 1), rt.total_factors);
     fill_info(rt, lo, hi, ws, info);
+    info->tape_mode = tm;
     return RYDIFF_OK;
 }
 

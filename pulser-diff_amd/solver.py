@@ -195,7 +195,7 @@ class _RydbergEvolve(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.stats = {"degree": info.degree, "total_factors": info.total_factors, "rho": info.rho_design,
                      "spectral": (info.spectral_lo, info.spectral_hi), "n_stages": info.n_stages,
-                     "tape": ("none", "steps", "full")[need_tape]}
+                     "tape": ("none", "steps", "full")[min(need_tape, info.tape_mode) if need_tape else 0]}
         spec.options["_last_stats"] = ctx.stats
         return states, expect
 

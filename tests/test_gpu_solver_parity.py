@@ -384,3 +384,29 @@ def test_real_amplitude_tables_give_the_real_part_of_the_gradient(cuda_device, n
     out[0][1] = out[0][1].real
     for name, ref, got in zip(("expect", "amp", "det", "u", "tsave", "psi0"), out[0], out[1]):
         assert rel_err(got.numpy(), ref.numpy()) < 1e-11, name
+
+
+def test_automatic_kernel_choice_by_tiles_in_flight(cuda_device):
+    """One 14-qubit trajectory (4 tiles) runs on the direct kernels: a requested full tape is granted as one state per tsave
+    (RydPlanInfo.tape_mode); 16 such trajectories (2^18 amplitudes in flight) take the chained tiles and get the full tape.
+    Same gradients per trajectory either way."""
+    from pulser_diff_amd.solver import ProblemSpec, SolverType, evolve
+
+    n = 14
+    terms = random_terms(n, 9, 0.002, seed=31, local=False)
+    amp, det, u, spec0 = to_native(terms, cuda_device, SolverType.KRYLOV_SE, store_states=False)
+    tsave = torch.linspace(0, 0.014, 4, dtype=torch.float64)
+    psi0 = R.all_ground_state(n).T.contiguous().to(cuda_device)
+    obs = R.total_magnetization_diag(n)[None].to(cuda_device)
+    grads = {}
+    for batch in (1, 16):
+        spec = ProblemSpec(n, spec0.dt, spec0.n_samples, spec0.amp_masks, spec0.det_masks, solver=SolverType.KRYLOV_SE,
+                           store_states=False, tape="full")
+        a = amp.clone().requires_grad_(True)
+        d = det.clone().requires_grad_(True)
+        _, expect = evolve(a, d, u, tsave, psi0.repeat(batch, 1), spec, obs)
+        expect[0, -1, :].sum().backward()
+        assert spec.options["_last_stats"]["tape"] == ("steps" if batch == 1 else "full")
+        grads[batch] = (expect[0, :, 0].detach().cpu().numpy(), a.grad.cpu().numpy() / batch, d.grad.cpu().numpy() / batch)
+    for x, y in zip(grads[1], grads[16]):
+        assert rel_err(y, x) < 1e-10
