@@ -47,6 +47,7 @@ __device__ __forceinline__ double2 pair_apply_tile(const PairArgs& pa, int which
 struct PersistArgs {
     const double2* psi0;      // [B][dim]
     double2* states;          // [n_tsave][B][dim] or nullptr
+    double2* tape_all;        // full tape [(n_factors + 1)][B][dim] (entry g + 1 = output of factor g) or nullptr
     const double* udiag;      // [dim]
     const double* coef;       // [Bc][E][NC]
     long coef_bstride;
@@ -195,6 +196,11 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist(P
             for (int r = 0; r < R; ++r) {
                 v[r] = q[r];
                 if (!lanes) tile[unsigned(r) * NT + tid] = q[r];
+            }
+            if (a.tape_all) {  // full tape: the adjoint sweep (per-factor launches at 12 qubits) recomputes nothing
+                double2* dst = a.tape_all + (size_t(f + 1) * a.B + b) * a.dim;
+#pragma unroll
+                for (int r = 0; r < R; ++r) dst[unsigned(r) * NT + tid] = v[r];
             }
         }
         if (pf.save_index) {

@@ -841,10 +841,10 @@ bool few_tiles(const Plan& pl, bool with_gradients) {
     return (size_t(pl.B) << pl.N) <= (size_t(1) << (with_gradients ? 17 : 18));
 }
 
-// the full per-factor tape exists only where the chained tile passes run
-bool full_tape_possible(const Plan& pl) {
-    return pl.N > kTileBitsHost && pl.N <= 28 && pl.n_pair == 0 && g_kernel_variant != 1 && g_kernel_variant != 5 && !few_tiles(pl, true);
-}
+// The full per-factor tape (the adjoint sweep recomputes nothing) goes with the launch-per-factor ADJOINT kernels, chained or
+// direct (12 qubits: the one-launch forward sweep writes it); up to 11 qubits the adjoint sweep is one launch too and keeps
+// one state per tsave.
+bool full_tape_possible(const Plan& pl) { return pl.N > kPersistBwdMaxQubits && pl.n_pair == 0; }
 
 // common prologue of forward / backward: plan, (optional) stats, carve, upload metadata, expand coefficients, udiag
 int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_t workspace_bytes, int need_tape,
@@ -1641,7 +1641,9 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
         HIP_TRY(hipStreamSynchronize(stream));
         PersistArgs pa{};
         pa.psi0 = static_cast<const double2*>(psi0);
-        pa.states = tape;
+        const bool full = pl.tape_mode == 2 && !states_out && tape;
+        pa.states = full ? nullptr : tape;
+        pa.tape_all = full ? tape : nullptr;
         pa.udiag = reinterpret_cast<const double*>(ws + pl.off_udiag);
         pa.coef = reinterpret_cast<const double*>(ws + pl.off_coef);
         pa.coef_bstride = pl.Bc > 1 ? long(pl.stages.size()) * pl.NC : 0;
@@ -1697,12 +1699,15 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
         return RYDIFF_OK;
     }
     int pp = 0;
+    const bool full_tape_direct = (pl.tape_mode == 2) && !states_out && tape;
+    size_t gfac = 0;  // global factor index: with the full tape entry g + 1 = output of factor g (entry 0 = psi0)
     for (int k = 0; k < pl.T; ++k) {
         build_step_chain(rt, k, chain);
-        for (size_t i = 0; i < chain.size(); ++i) {
+        for (size_t i = 0; i < chain.size(); ++i, ++gfac) {
             const bool last = (i + 1 == chain.size());
             double2* dst;
-            if (last && tape) dst = tape + size_t(k + 1) * sv;
+            if (full_tape_direct) dst = tape + (gfac + 1) * sv;
+            else if (last && tape) dst = tape + size_t(k + 1) * sv;
             else {
                 dst = buf[pp];
                 if (dst == cur) dst = buf[pp ^ 1];

@@ -387,9 +387,9 @@ def test_real_amplitude_tables_give_the_real_part_of_the_gradient(cuda_device, n
 
 
 def test_automatic_kernel_choice_by_tiles_in_flight(cuda_device):
-    """One 14-qubit trajectory (4 tiles) runs on the direct kernels: a requested full tape is granted as one state per tsave
-    (RydPlanInfo.tape_mode); 16 such trajectories (2^18 amplitudes in flight) take the chained tiles and get the full tape.
-    Same gradients per trajectory either way."""
+    """One 14-qubit trajectory (4 tiles) runs on the direct kernels, 16 such trajectories (2^18 amplitudes in flight) on the
+    chained tiles; both keep the full per-factor tape when asked to (RydPlanInfo.tape_mode), and give the same gradients
+    per trajectory."""
     from pulser_diff_amd.solver import ProblemSpec, SolverType, evolve
 
     n = 14
@@ -406,7 +406,7 @@ def test_automatic_kernel_choice_by_tiles_in_flight(cuda_device):
         d = det.clone().requires_grad_(True)
         _, expect = evolve(a, d, u, tsave, psi0.repeat(batch, 1), spec, obs)
         expect[0, -1, :].sum().backward()
-        assert spec.options["_last_stats"]["tape"] == ("steps" if batch == 1 else "full")
+        assert spec.options["_last_stats"]["tape"] == "full"
         grads[batch] = (expect[0, :, 0].detach().cpu().numpy(), a.grad.cpu().numpy() / batch, d.grad.cpu().numpy() / batch)
     for x, y in zip(grads[1], grads[16]):
         assert rel_err(y, x) < 1e-10
