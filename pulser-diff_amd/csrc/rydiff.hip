@@ -1987,7 +1987,7 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
         sa.det = p->det_tables;
         sa.g_amp = static_cast<double2*>(g_amp);
         sa.g_det = g_det;
-        sa.g_tsave = (pl.Bc == 1 || true) ? g_tsave : nullptr;
+        sa.g_tsave = g_tsave;
         sa.E = int(E);
         sa.n_samples = pl.n_samples;
         sa.Ka = pl.Ka;
