@@ -93,3 +93,33 @@ def test_unparametrized_sequence_and_register_reconstruction():
     rebuilt = model._construct_register()
     assert rebuilt.qubit_ids == reg.qubit_ids
     assert all(torch.allclose(rebuilt.qubits[k], reg.qubits[k]) for k in reg.qubit_ids)
+
+
+def test_constant_pulse_envelope():
+    """The reference's tests/test_waveform_funcs.py::test_constant_pulse on the host mirror: the tanh-edged envelope of a
+    constant pulse between ti and tf (us) averages to `value` over its plateau (ATOL_ENV = 5e-2, tests/metrics.py:14), is
+    evaluated for all sample times in ONE call here, and is differentiable w.r.t. both edges and the height."""
+    from pulser_diff_amd.waveform_funcs import constant_waveform
+
+    torch.manual_seed(3)
+    ti_val = torch.rand(1, dtype=torch.float64).requires_grad_(True)
+    tf_val = (ti_val.detach() + torch.rand(1, dtype=torch.float64) + 0.3).requires_grad_(True)
+    value_val = (torch.rand(1, dtype=torch.float64) * 5 + 1).requires_grad_(True)
+    envelope = constant_waveform(ti_val, tf_val, value_val)
+    t = torch.arange(int(ti_val.detach() * 1000), int(tf_val.detach() * 1000), dtype=torch.float64)
+    wf = envelope(t)
+    assert abs(float(value_val.detach()) - float(wf.detach().mean())) < 5e-2
+    # one value per ns, the same numbers as the reference's one-call-per-ns loop
+    per_ns = torch.stack([envelope(torch.tensor(float(k), dtype=torch.float64)) for k in range(int(t[0]), int(t[0]) + 5)]).reshape(-1)
+    assert torch.allclose(per_ns, wf[:5], atol=1e-14)
+    # a pulse that starts the sequence has no rising edge (waveform_funcs.py:17-18)
+    first = constant_waveform(0, tf_val, value_val)(torch.tensor([0.0, 1.0], dtype=torch.float64))
+    assert torch.allclose(first, value_val.detach().expand(2), atol=1e-9)
+    total = constant_waveform(ti_val, tf_val, value_val)(torch.arange(0, 3000, dtype=torch.float64)).sum()
+    g_ti, g_tf, g_v = torch.autograd.grad(total, (ti_val, tf_val, value_val))
+    # area = value * (tf - ti) * 1000 samples (up to the 1-ns sampling of the edges): d/dtf = +1000 value, d/dti = -1000 value,
+    # d/dvalue = 1000 (tf - ti)
+    v, span = float(value_val.detach()), float((tf_val - ti_val).detach())
+    assert abs(float(g_tf) - 1000 * v) < 1e-2 * 1000 * v
+    assert abs(float(g_ti) + 1000 * v) < 1e-2 * 1000 * v
+    assert abs(float(g_v) - 1000 * span) < 1e-2 * 1000 * span
