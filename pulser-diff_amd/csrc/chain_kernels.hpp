@@ -127,7 +127,7 @@ __device__ __forceinline__ void park1(double v0, double* red, int slot0) {
 }
 
 // partner sums over the tile bits in `mask`:  ts[r] = sum of partners, ds[r] = sum(+partner if own bit set else -partner)
-template <int LT, int LGT, bool CPLX>
+template <int LT, int LGT, bool CPLX, bool FULL = false>  // FULL: every tile bit is in the mask (no per-bit tests)
 __device__ __forceinline__ void partner_sums(const double2* __restrict__ tile, const double2 (&reg)[1 << (LT - LGT)],
                                              uint32_t mask, unsigned tid, double2 (&ts)[1 << (LT - LGT)],
                                              double2 (&ds)[1 << (LT - LGT)]) {
@@ -139,7 +139,7 @@ __device__ __forceinline__ void partner_sums(const double2* __restrict__ tile, c
     }
 #pragma unroll
     for (int b = 0; b < LT; ++b) {
-        if (mask >> b & 1u) {  // wave-uniform
+        if (FULL || (mask >> b & 1u)) {  // wave-uniform
             if (b < LGT) {
                 const double sgn = (tid >> b & 1u) ? 1.0 : -1.0;
 #pragma unroll

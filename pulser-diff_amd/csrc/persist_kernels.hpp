@@ -83,8 +83,11 @@ __device__ __forceinline__ void stage_factors(const PersistFactor* __restrict__ 
 // SMALLG: at most kPersistGroups amplitude and detuning groups — group loops are unrolled (masks / counts stay in
 // scalar registers instead of being re-read from the kernel-argument segment every factor) and the coefficient
 // records come from the LDS stage; otherwise generic loops over up to kMaxGroups groups with coefficients from global.
-template <int LT, int LGT, bool CPLX, bool SMALLG>
+// FAST (implies SMALLG): one amplitude group driving every qubit (a global channel) and at most one detuning group — no
+// group loops, no mask tests.
+template <int LT, int LGT, bool CPLX, bool SMALLG, bool FAST = false>
 __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist(PersistArgs a) {
+    constexpr int GL = FAST ? 1 : kPersistGroups;
     constexpr int NT = 1 << LGT, R = 1 << (LT - LGT), NTL = NT < 64 ? 64 : NT, NW = NTL / 64;
     __shared__ __attribute__((aligned(16))) double2 tile[1 << LT];
     __shared__ double red[NW];
@@ -143,7 +146,7 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist(P
             };
             if constexpr (SMALLG) {
 #pragma unroll
-                for (int g = 0; g < kPersistGroups; ++g)
+                for (int g = 0; g < GL; ++g)
                     if (g < a.gd) det_group(g);
             } else {
                 for (int g = 0; g < a.gd; ++g) det_group(g);
@@ -157,10 +160,10 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist(P
             auto amp_group = [&](int g) {
                 double2 ts[R], ds[R];
                 if constexpr (LT <= 6) {
-                    if (lanes) partner_sums_lanes<LT, CPLX>(v[0], a.amask[g], tid, ts[0], ds[0]);
-                    else partner_sums<LT, LGT, CPLX>(tile, v, a.amask[g], tid, ts, ds);
+                    if (lanes) partner_sums_lanes<LT, CPLX, FAST>(v[0], a.amask[g], tid, ts[0], ds[0]);
+                    else partner_sums<LT, LGT, CPLX, FAST>(tile, v, a.amask[g], tid, ts, ds);
                 } else {
-                    partner_sums<LT, LGT, CPLX>(tile, v, a.amask[g], tid, ts, ds);
+                    partner_sums<LT, LGT, CPLX, FAST>(tile, v, a.amask[g], tid, ts, ds);
                 }
                 const double cr = cf(g), ci = cf(a.ga + g);
                 const double k1r = pf.br * cr, k1i = pf.bi * cr, k2r = -pf.bi * ci, k2i = pf.br * ci;
@@ -176,8 +179,8 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist(P
             };
             if constexpr (SMALLG) {
 #pragma unroll
-                for (int g = 0; g < kPersistGroups; ++g)
-                    if (g < a.ga) amp_group(g);
+                for (int g = 0; g < GL; ++g)
+                    if (FAST || g < a.ga) amp_group(g);
             } else {
                 for (int g = 0; g < a.ga; ++g) amp_group(g);
             }
@@ -272,8 +275,9 @@ struct PersistBwdArgs {
     PairArgs pair;
 };
 
-template <int LT, int LGT, bool CPLX>
+template <int LT, int LGT, bool CPLX, bool FAST = false>  // FAST: one global drive, at most one detuning group (as in k_persist)
 __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist_bwd(PersistBwdArgs a) {
+    constexpr int GL = FAST ? 1 : kPersistGroups;
     constexpr int NT = 1 << LGT, R = 1 << (LT - LGT), NTL = NT < 64 ? 64 : NT, NW = NTL / 64;
     constexpr int NV = 3 * kPersistGroups + 1;
     constexpr int PARK = (1 << LT) <= kParkAmps ? kParkAmps : 1;   // parked factor inputs (amplitudes) in LDS
@@ -405,21 +409,21 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist_b
                     const unsigned x = unsigned(r) * NT + tid;
                     double d = ud[r];
 #pragma unroll
-                    for (int g = 0; g < kPersistGroups; ++g)
+                    for (int g = 0; g < GL; ++g)
                         if (g < a.gd) d += cf[2 * a.ga + g] * double(a.dcnt[g] - __popc(x & a.dmask[g]));
                     const double dr = pf.gr + pf.br * d, di = pf.gi + pf.bi * d;
                     q[r].x = dr * v[r].x - di * v[r].y;
                     q[r].y = dr * v[r].y + di * v[r].x;
                 }
 #pragma unroll
-                for (int g = 0; g < kPersistGroups; ++g) {
-                    if (g < a.ga) {
+                for (int g = 0; g < GL; ++g) {
+                    if (FAST || g < a.ga) {
                         double2 ts[R], ds[R];
                         if constexpr (LT <= 6) {
-                            if (lanes) partner_sums_lanes<LT, CPLX>(v[0], a.amask[g], tid, ts[0], ds[0]);
-                            else partner_sums<LT, LGT, CPLX>(tile, v, a.amask[g], tid, ts, ds);
+                            if (lanes) partner_sums_lanes<LT, CPLX, FAST>(v[0], a.amask[g], tid, ts[0], ds[0]);
+                            else partner_sums<LT, LGT, CPLX, FAST>(tile, v, a.amask[g], tid, ts, ds);
                         } else {
-                            partner_sums<LT, LGT, CPLX>(tile, v, a.amask[g], tid, ts, ds);
+                            partner_sums<LT, LGT, CPLX, FAST>(tile, v, a.amask[g], tid, ts, ds);
                         }
                         const double cr = cf[g], ci = cf[a.ga + g];
                         const double k1r = pf.br * cr, k1i = pf.bi * cr, k2r = -pf.bi * ci, k2i = pf.br * ci;
@@ -481,7 +485,7 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist_b
                     const unsigned x = unsigned(r) * NT + tid;
                     double d = ud[r];
 #pragma unroll
-                    for (int g = 0; g < kPersistGroups; ++g)
+                    for (int g = 0; g < GL; ++g)
                         if (g < a.gd) d += cf[2 * a.ga + g] * double(a.dcnt[g] - __popc(x & a.dmask[g]));
                     hm[r].x = d * mu[r].x;
                     hm[r].y = d * mu[r].y;
@@ -489,20 +493,20 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist_b
                     const double rr = pr * v[r].x - pi * v[r].y;  // Re(beta conj(mu) x)
                     wt[r] += rr;
 #pragma unroll
-                    for (int g = 0; g < kPersistGroups; ++g)
+                    for (int g = 0; g < GL; ++g)
                         if (g < a.gd) acc_det[g] += rr * double(a.dcnt[g] - __popc(x & a.dmask[g]));
                 }
 #pragma unroll
-                for (int g = 0; g < kPersistGroups; ++g) {
-                    if (g < a.ga) {
+                for (int g = 0; g < GL; ++g) {
+                    if (FAST || g < a.ga) {
                         const double cr = cf[g], ci = cf[a.ga + g];
                         double z1r = 0.0, z1i = 0.0, z2r = 0.0, z2i = 0.0;
                         double2 ts[R], ds[R];
                         if constexpr (LT <= 6) {
-                            if (lanes) partner_sums_lanes<LT, true>(mu[0], a.amask[g], tid, ts[0], ds[0]);
-                            else partner_sums<LT, LGT, true>(tile, mu, a.amask[g], tid, ts, ds);
+                            if (lanes) partner_sums_lanes<LT, true, FAST>(mu[0], a.amask[g], tid, ts[0], ds[0]);
+                            else partner_sums<LT, LGT, true, FAST>(tile, mu, a.amask[g], tid, ts, ds);
                         } else {
-                            partner_sums<LT, LGT, true>(tile, mu, a.amask[g], tid, ts, ds);
+                            partner_sums<LT, LGT, true, FAST>(tile, mu, a.amask[g], tid, ts, ds);
                         }
 #pragma unroll
                         for (int r = 0; r < R; ++r) {
@@ -554,6 +558,7 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist_b
                 acc_tau = 0.0;
 #pragma unroll
                 for (int q = 0; q < NV; ++q) {
+                    if (FAST && q != 3 * kPersistGroups && (q % kPersistGroups) != 0) continue;  // only group 0 exists
                     double s = vals[q];
 #pragma unroll
                     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
