@@ -242,9 +242,13 @@ __device__ unsigned long long g_timeline[4096 * 8];  // tuning builds: per-workg
 #define RYDIFF_TL(slot)
 #endif
 
-template <int LT, int LGT, bool CPLX, bool BWD>
+// FAST: exactly one amplitude group, every tile bit in its start-stage mask and no partner-tile loads (a global drive), at
+// most one detuning group: straight-line code instead of the runtime group loops, no mask tests in the start stage.
+template <int LT, int LGT, bool CPLX, bool BWD, bool FAST = false>
 __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     constexpr int NT = 1 << LGT, R = 1 << (LT - LGT);
+    const int GA = FAST ? 1 : a.ga;            // amplitude groups looped over
+    const int GD = FAST ? (a.gd ? 1 : 0) : a.gd;
     extern __shared__ __attribute__((aligned(16))) double2 tile[];
     // behind the tile: NT/64 doubles (forward: fused expectation) or [4 ga + gd][NT/64] parked gradient partials (adjoint)
     double* red = reinterpret_cast<double*>(tile + (size_t(1) << LT));
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
 
     if (a.has_p) {
         const double* __restrict__ cf = a.coef_fin + blockIdx.y * a.coef_bstride;
-        for (int g = 0; g < a.ga; ++g) {
+        for (int g = 0; g < GA; ++g) {
             const uint32_t mask = a.fin_mask[g];
             if (!mask) continue;
             double2 ts[R], ds[R];
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
             rr[r] = pr * xs[r].x - pi * xs[r].y;
             if (a.wtot) unsafeAtomicAdd(a.wtot + xg[r], rr[r]);
         }
-        for (int g = 0; g < a.gd; ++g) {
+        for (int g = 0; g < GD; ++g) {
             double sgd = 0.0;
 #pragma unroll
             for (int r = 0; r < R; ++r) sgd += rr[r] * double(a.dcnt[g] - __popc(xg[r] & a.dmask[g]));
@@ -441,22 +445,26 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
 #pragma unroll
         for (int b2 = LGT; b2 < LT; ++b2)
             if (!(r >> (b2 - LGT) & 1)) d += vloc[b2];
-        for (int g = 0; g < a.gd; ++g) d += cf[2 * a.ga + g] * double(a.dcnt[g] - __popc(xg[r] & a.dmask[g]));
+        if (FAST) {
+            if (GD) d += cf[2] * double(a.dcnt[0] - __popc(xg[r] & a.dmask[0]));
+        } else {
+            for (int g = 0; g < a.gd; ++g) d += cf[2 * a.ga + g] * double(a.dcnt[g] - __popc(xg[r] & a.dmask[g]));
+        }
         const double dr = a.sg_r + a.sb_r * d, di = a.sg_i + a.sb_i * d;
         q[r].x = dr * acc[r].x - di * acc[r].y;
         q[r].y = dr * acc[r].y + di * acc[r].x;
     }
-    for (int g = 0; g < a.ga; ++g) {
+    for (int g = 0; g < GA; ++g) {
         const uint32_t mask = a.sta_mask[g];
-        if (!mask && !a.hi_mask[g]) continue;
+        if (!FAST && !mask && !a.hi_mask[g]) continue;
         double2 ts[R], ds[R];
 #ifndef RYDIFF_ABLATE_COMPUTE
-        partner_sums<LT, LGT, CPLX>(tile, acc, mask, tid, ts, ds);
+        partner_sums<LT, LGT, CPLX, FAST>(tile, acc, mask, tid, ts, ds);
 #else
         for (int r = 0; r < R; ++r) { ts[r] = acc[r]; ds[r] = acc[r]; }
 #endif
         {   // single-pass mode: partner tiles for the index bits outside this tile (coalesced 16-B loads, same offsets)
-            uint32_t hm = a.hi_mask[g];
+            uint32_t hm = FAST ? 0u : a.hi_mask[g];
             while (hm) {
                 const uint32_t bit = hm & (0u - hm);
                 hm ^= bit;

@@ -1061,14 +1061,18 @@ struct ChainStep {
     long exp_ostride = 0;
 };
 
-template <int LGT, bool CPLX, bool BWD>
+template <int LGT, bool CPLX, bool BWD, bool FAST = false>
 int launch_chain_t(const ChainArgs& ca, unsigned tiles, int B, hipStream_t stream) {
+    if constexpr (!FAST) {  // one global drive, at most one detuning group, no partner-tile loads: the loop-free instantiation
+        if (ca.ga == 1 && ca.gd <= 1 && ca.sta_mask[0] == (1u << kTileBits) - 1u && ca.hi_mask[0] == 0)
+            return launch_chain_t<LGT, CPLX, BWD, true>(ca, tiles, B, stream);
+    }
     static bool attr_set = false;
     // tile + reduction scratch: one double per wave (forward), [4 ga + gd] slots per wave (adjoint: parked gradient partials)
     const size_t nw = (size_t(1) << LGT) / 64;
     const size_t max_lds = (size_t(1) << kTileBits) * sizeof(double2) + 256 + (BWD ? size_t(5) * kMaxGroups * nw * sizeof(double) : 0);
     const size_t lds = (size_t(1) << kTileBits) * sizeof(double2) + 256 + (BWD ? size_t(4 * ca.ga + ca.gd) * nw * sizeof(double) : 0);
-    auto kern = k_chain<kTileBits, LGT, CPLX, BWD>;
+    auto kern = k_chain<kTileBits, LGT, CPLX, BWD, FAST>;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(max_lds)));
         attr_set = true;
