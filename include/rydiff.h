@@ -179,7 +179,8 @@ int rydiff_design_polynomial(double rho, double tol, int max_degree, int* degree
  * 2 / 3 / 4 = LDS-tiled chained passes with 512 / 256 / 1024 threads per tile (13 <= N <= 28; two tile layouts up to
  * N = 22, three from N = 23), 5 = single-pass tiles with partner-tile loads, 6 = sub-tile pipelined chain (N <= 22),
  * 7 = auto with three tile layouts wherever they are legal (21 <= N <= 28), 8 = auto with the LDS-tile persistent kernels
- * also up to 6 qubits (instead of the one-wave lane kernels).  "auto" takes the one-launch sweeps up to 12 qubits, the direct
+ * also up to 6 qubits (instead of the one-wave lane kernels), 9 = direct as 1 but always the generic kernels (without the
+ * unrolled instantiations for one global drive on 12..20 qubits).  "auto" takes the one-launch sweeps up to 12 qubits, the direct
  * kernels while few tiles are in flight (B * 2^N <= 2^18 forward-only, 2^17 with gradients) and the chained passes beyond.
  * Used by parity tests to A/B the kernels against each other and by the tuning scripts. */
 int rydiff_set_kernel_variant(int variant);

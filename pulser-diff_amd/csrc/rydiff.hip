@@ -38,6 +38,7 @@ constexpr int kMaxRemote = 6;  // up to 2^6 GPUs in a state-sharded run
 
 static thread_local std::string g_last_error;
 static int g_kernel_variant = 0;
+static int g_generic_direct = 0;  // kernel variant 9: direct kernels WITHOUT the unrolled global-drive instantiations (A/B reference)
 #ifndef RYDIFF_TILE_BITS
 #define RYDIFF_TILE_BITS 12
 #endif
@@ -473,6 +474,85 @@ __global__ __launch_bounds__(256) void k_factor_bwd_direct(FactorBwdArgs a) {
     if (live) a.gout[boff + x] = make_double2(ar, ai);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Direct kernels for ONE GLOBAL DRIVE on a register of exactly NQ qubits (every bit in the amplitude mask; no remote
+// vectors, no pair terms).  The generic kernels above walk the set bits of a runtime mask: one partner load, one wait per bit
+// — on 13..18 qubits, where a pass is a few microseconds, that chain of N dependent L2 latencies IS the kernel time.  Here the
+// loop over the NQ bits is unrolled, so all partner loads are in flight together and the plain / signed partner sums replace
+// the per-bit branch (c*s1 + conj(c)*s0 = cr*(s1+s0) + i*ci*(s1-s0)).
+// ------------------------------------------------------------------------------------------------
+template <int NQ>
+__global__ __launch_bounds__(256) void k_factor_direct_global(FactorArgs a) {
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;  // dim = 2^NQ is a multiple of 256
+    const size_t boff = size_t(blockIdx.y) * a.dim;
+    const double2* __restrict__ xin = a.xin + boff;
+    const double* __restrict__ cf = a.use_inline ? a.coef_inline : a.coef + blockIdx.y * a.coef_bstride;
+    double2 p[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) p[j] = xin[x ^ (1u << j)];
+    const double2 v = xin[x];
+    const double d = diag_value(a.udiag, cf, a.g, x);
+    double tsr = 0.0, tsi = 0.0, dsr = 0.0, dsi = 0.0;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const double sgn = (x >> j & 1u) ? 1.0 : -1.0;
+        tsr += p[j].x;
+        tsi += p[j].y;
+        dsr = fma(sgn, p[j].x, dsr);
+        dsi = fma(sgn, p[j].y, dsi);
+    }
+    const double dr = a.gr + a.br * d, di = a.gi + a.bi * d;
+    const double cr = cf[0], ci = cf[1];
+    // F = cr*ts + i*ci*ds
+    const double fr = cr * tsr - ci * dsi, fi = cr * tsi + ci * dsr;
+    a.xout[boff + x] = make_double2(dr * v.x - di * v.y + a.br * fr - a.bi * fi, dr * v.y + di * v.x + a.br * fi + a.bi * fr);
+}
+
+template <int NQ>
+__global__ __launch_bounds__(256) void k_factor_bwd_direct_global(FactorBwdArgs a) {
+    __shared__ double lds[8];
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    const size_t boff = size_t(blockIdx.y) * a.dim;
+    const double2* __restrict__ gin = a.gin + boff;
+    const double2* __restrict__ xin = a.xin + boff;
+    const double* __restrict__ cf = a.coef + blockIdx.y * a.coef_bstride;
+    double* __restrict__ ge = a.ge + blockIdx.y * a.ge_bstride + (blockIdx.x % kGradReplicas) * a.ge_rstride;
+    double2 pg[NQ], px[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        pg[j] = gin[x ^ (1u << j)];
+        px[j] = xin[x ^ (1u << j)];
+    }
+    const double2 gy = gin[x], xi = xin[x];
+    const double d = diag_value(a.udiag, cf, a.g, x);
+    double gsr = 0.0, gsi = 0.0, gdr = 0.0, gdi = 0.0;  // plain / signed partner sums of the cotangent
+    double xsr = 0.0, xsi = 0.0, xdr = 0.0, xdi = 0.0;  // ... of the factor input
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const double sgn = (x >> j & 1u) ? 1.0 : -1.0;
+        gsr += pg[j].x;
+        gsi += pg[j].y;
+        gdr = fma(sgn, pg[j].x, gdr);
+        gdi = fma(sgn, pg[j].y, gdi);
+        xsr += px[j].x;
+        xsi += px[j].y;
+        xdr = fma(sgn, px[j].x, xdr);
+        xdi = fma(sgn, px[j].y, xdi);
+    }
+    const double cr = cf[0], ci = cf[1];
+    // adjoint matvec: conj(gamma + beta d) gy + conj(beta) (cr*gs + i*ci*gd)
+    const double dr = a.gr + a.br * d, di = -(a.gi + a.bi * d);
+    const double fr = cr * gsr - ci * gdi, fi = cr * gsi + ci * gdr;
+    a.gout[boff + x] = make_double2(dr * gy.x - di * gy.y + a.br * fr + a.bi * fi, dr * gy.y + di * gy.x + a.br * fi - a.bi * fr);
+    // contractions with a_ = beta * conj(gy):  dL/dRe c = Re(a_ * xs),  dL/dIm c = -Im(a_ * xd)
+    const double pr = a.br * gy.x + a.bi * gy.y, pi = a.bi * gy.x - a.br * gy.y;
+    const double r = pr * xi.x - pi * xi.y;  // Re(beta conj(gy) xi)
+    if (a.wtot) unsafeAtomicAdd(a.wtot + x, r);
+    block_atomic_add(pr * xsr - pi * xsi, ge, lds);
+    block_atomic_add(-(pr * xdi + pi * xdr), ge + 1, lds);
+    for (int q = 0; q < a.g.gd; ++q) block_atomic_add(r * double(a.g.dcnt[q] - __popc(x & a.g.dmask[q])), ge + 2 + q, lds);
+}
+
 // dL/dtau of one exponential:  Re< g, -i H x >  = Im( sum_x conj(g[x]) (H x)[x] )
 struct DotHArgs {
     const double2* g;
@@ -834,11 +914,13 @@ void fill_info(const Runtime& rt, double lo, double hi, size_t ws, RydPlanInfo* 
 // A tile pass keeps one CU busy for ~10 us per tile whatever the register size, so with few tiles in flight (one 13..18-qubit
 // trajectory: 2..64 tiles on 256 CUs) the one-amplitude-per-thread kernels, which spread over the whole chip, are faster.
 // Measured crossover (tools/time_small.py, bench.py --workload c4 --batch b, variants 0 / 1): forward-only runs up to 2^18
-// amplitudes in flight (N=13: 5.3 vs 9.4 us per pass, N=16 B=4: +13 %), runs with gradients up to 2^17 (N=13: 52 vs 104 ms,
-// N=16 B=2: +5 %; at 2^18 the full tape already wins for a batch).  Explicit kernel variants are left alone (A/B tests).
+// amplitudes in flight (N=13: 5.3 vs 9.4 us per pass, N=16 B=4: +13 %), and the same with gradients since the direct kernels
+// keep the full tape too and have unrolled instantiations for one global drive (N=18, 200 steps: 50 ms vs 69 ms chained; N=19:
+// 83 vs 78 ms).  Explicit kernel variants are left alone (A/B tests).
 bool few_tiles(const Plan& pl, bool with_gradients) {
     if (g_kernel_variant != 0 || g_force_three_layouts) return false;
-    return (size_t(pl.B) << pl.N) <= (size_t(1) << (with_gradients ? 17 : 18));
+    (void)with_gradients;  // with the unrolled global-drive direct kernels the crossover is 2^18 amplitudes either way
+    return (size_t(pl.B) << pl.N) <= (size_t(1) << 18);
 }
 
 // The full per-factor tape (the adjoint sweep recomputes nothing) goes with the launch-per-factor ADJOINT kernels, chained or
@@ -972,6 +1054,12 @@ void build_step_chain(const Runtime& rt, int k, std::vector<ChainItem>& chain) {
 int launch_single_fwd(const Runtime& rt, char* ws, const double2* xin, double2* xout, int stage, const FactorScalars& s, hipStream_t stream);
 bool single_pass_enabled(const Runtime& rt);
 
+// one global drive on a 12..20-qubit register without pair terms: the unrolled direct kernels (k_factor_direct_global)
+bool direct_global_ok(const Plan& pl) {
+    return !g_generic_direct && pl.N >= 12 && pl.N <= 20 && pl.n_pair == 0 && pl.ga.n == 1 &&
+           pl.ga.amp_index_mask[0] == (1u << pl.N) - 1u;
+}
+
 int launch_factor(const Runtime& rt, char* ws, const double2* xin, double2* xout, int stage, const FactorScalars& s, hipStream_t stream) {
     const Plan& pl = rt.pl;
     if (single_pass_enabled(rt)) return launch_single_fwd(rt, ws, xin, xout, stage, s, stream);
@@ -989,7 +1077,15 @@ int launch_factor(const Runtime& rt, char* ws, const double2* xin, double2* xout
     fa.g = rt.garg;
     fa.pair = rt.parg;
     dim3 grid(unsigned((pl.dim + 255) / 256), pl.B);
-    hipLaunchKernelGGL(k_factor_direct, grid, dim3(256), 0, stream, fa);
+    if (direct_global_ok(pl)) {
+        switch (pl.N) {
+#define RYDIFF_CASE(NQ) case NQ: hipLaunchKernelGGL(k_factor_direct_global<NQ>, grid, dim3(256), 0, stream, fa); break;
+            RYDIFF_CASE(12) RYDIFF_CASE(13) RYDIFF_CASE(14) RYDIFF_CASE(15) RYDIFF_CASE(16) RYDIFF_CASE(17) RYDIFF_CASE(18) RYDIFF_CASE(19) RYDIFF_CASE(20)
+#undef RYDIFF_CASE
+        }
+    } else {
+        hipLaunchKernelGGL(k_factor_direct, grid, dim3(256), 0, stream, fa);
+    }
     LAUNCH_CHECK();
     return RYDIFF_OK;
 }
@@ -1566,8 +1662,11 @@ int rydiff_set_kernel_variant(int variant) {
     // 5 single-pass LDS tiles with partner-tile loads (forward / recompute passes; adjoint stays direct)
     // 6 chained tiles with sub-tile pipelining (13 <= N <= 22; experimental)
     // 8 LDS-tile persistent kernels also for N <= 6 (A/B reference of the one-wave lane kernels)
+    // 9 direct kernels as 1, but always the generic ones (A/B reference of the unrolled global-drive instantiations)
     // 7 auto, but three tile layouts wherever they are legal (21 <= N <= 28; default from N = 23)
-    if (variant < 0 || variant > 8) return fail(RYDIFF_EINVAL, "kernel variant must be 0..8");
+    if (variant < 0 || variant > 9) return fail(RYDIFF_EINVAL, "kernel variant must be 0..9");
+    g_generic_direct = variant == 9;
+    if (variant == 9) variant = 1;
     g_force_three_layouts = variant == 7;
     if (variant == 7) variant = 0;
     g_kernel_variant = variant;
@@ -1948,7 +2047,15 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
             ba.bi = it.s.bi;
             ba.g = rt.garg;
             ba.pair = rt.parg;
-            hipLaunchKernelGGL(k_factor_bwd_direct, grid, dim3(256), 0, stream, ba);
+            if (direct_global_ok(pl)) {
+                switch (pl.N) {
+#define RYDIFF_CASE(NQ) case NQ: hipLaunchKernelGGL(k_factor_bwd_direct_global<NQ>, grid, dim3(256), 0, stream, ba); break;
+                    RYDIFF_CASE(12) RYDIFF_CASE(13) RYDIFF_CASE(14) RYDIFF_CASE(15) RYDIFF_CASE(16) RYDIFF_CASE(17) RYDIFF_CASE(18) RYDIFF_CASE(19) RYDIFF_CASE(20)
+#undef RYDIFF_CASE
+                }
+            } else {
+                hipLaunchKernelGGL(k_factor_bwd_direct, grid, dim3(256), 0, stream, ba);
+            }
             LAUNCH_CHECK();
             cl ^= 1;
         }
