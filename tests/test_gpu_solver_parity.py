@@ -410,3 +410,22 @@ def test_automatic_kernel_choice_by_tiles_in_flight(cuda_device):
         grads[batch] = (expect[0, :, 0].detach().cpu().numpy(), a.grad.cpu().numpy() / batch, d.grad.cpu().numpy() / batch)
     for x, y in zip(grads[1], grads[16]):
         assert rel_err(y, x) < 1e-10
+
+
+@pytest.mark.parametrize("n_qubits", [12, 14, 17, 19])
+def test_unrolled_global_drive_direct_kernels_match_generic_ones(cuda_device, n_qubits):
+    """One global drive on 12..20 qubits: the direct kernels with the loop over the N partner bits unrolled (all loads in
+    flight, plain / signed partner sums) against the generic direct kernels (variant 9), complex coefficients, states,
+    expectation values and gradients."""
+    terms = random_terms(n_qubits, 17, 0.002, seed=600 + n_qubits, local=False)
+    tsave = torch.linspace(0, 0.03, 7, dtype=torch.float64)
+    gen = torch.Generator().manual_seed(n_qubits)
+    psi = torch.randn(1, 2**n_qubits, generator=gen, dtype=torch.complex128)
+    psi = (psi / psi.norm()).to(cuda_device)
+    obs = R.total_magnetization_diag(n_qubits)[None].to(cuda_device)
+    ref = _run_variant(9, terms, tsave, psi, cuda_device, obs)
+    got = _run_variant(1, terms, tsave, psi, cuda_device, obs)
+    assert rel_err(got["states"].cpu().numpy(), ref["states"].cpu().numpy()) < 1e-12
+    assert np.abs((got["expect"] - ref["expect"]).cpu().numpy()).max() < 1e-10
+    for key in ("amp", "det", "u"):
+        assert rel_err(got[key].cpu().numpy(), ref[key].cpu().numpy()) < 1e-10, key
