@@ -42,6 +42,51 @@ __device__ __forceinline__ double lanes_sum(double x) {
     return x;
 }
 
+// Dense two-qubit terms (master equation on the doubled register: <= 3 physical qubits here, so <= 3 pair terms).  The 4x4
+// block of term t couples x with the three lanes x ^ mb, x ^ ma, x ^ (ma | mb); each lane keeps ITS row of the (constant)
+// block in registers, permuted so that entry delta multiplies the amplitude of lane x ^ D(delta).
+constexpr int kLanePairMax = 3;
+
+struct LanePairs {
+    int n;
+    int d[kLanePairMax][3];        // lane offsets D(1) = mb, D(2) = ma, D(3) = ma | mb
+    double2 c[kLanePairMax][4];    // row of the block: c[t][delta] = T_t[4 * own + (delta ^ own)]
+
+    __device__ __forceinline__ void load(const PairArgs& pa, int which, unsigned lane) {
+        n = pa.n < kLanePairMax ? pa.n : kLanePairMax;
+#pragma unroll
+        for (int t = 0; t < kLanePairMax; ++t) {
+            const uint32_t ma = t < n ? pa.ma[t] : 0u, mb = t < n ? pa.mb[t] : 0u;
+            const int own = ((lane & ma) ? 2 : 0) | ((lane & mb) ? 1 : 0);
+            d[t][0] = int(mb);
+            d[t][1] = int(ma);
+            d[t][2] = int(ma | mb);
+#pragma unroll
+            for (int dl = 0; dl < 4; ++dl)
+                c[t][dl] = t < n ? pa.tab[(t * 2 + which) * 16 + own * 4 + (dl ^ own)] : make_double2(0.0, 0.0);
+        }
+    }
+    // sum_t sum_s T_t[4 * own + s] * v[x with the pair's bits set to s]
+    __device__ __forceinline__ double2 apply(const double2& v, unsigned lane) const {
+        double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int t = 0; t < kLanePairMax; ++t) {
+            if (t < n) {  // wave-uniform
+                acc.x += c[t][0].x * v.x - c[t][0].y * v.y;
+                acc.y += c[t][0].x * v.y + c[t][0].y * v.x;
+#pragma unroll
+                for (int dl = 1; dl < 4; ++dl) {
+                    const int src = int(lane) ^ d[t][dl - 1];
+                    const double qx = __shfl(v.x, src, 64), qy = __shfl(v.y, src, 64);
+                    acc.x += c[t][dl].x * qx - c[t][dl].y * qy;
+                    acc.y += c[t][dl].x * qy + c[t][dl].y * qx;
+                }
+            }
+        }
+        return acc;
+    }
+};
+
 // scalars of one factor as the loop needs them: gamma, beta and beta times every coefficient of the factor's exponential
 struct LaneRec {
     double gr, gi, br, bi;
@@ -101,6 +146,8 @@ __global__ __launch_bounds__(64) void k_lanes_fwd(PersistArgs a) {
         ud = a.udiag[lane];
         if (a.n_obs > 0) ob0 = a.obs[lane];
     }
+    LanePairs pairs;
+    pairs.load(a.pair, 0, lane);
     LaneRecLoader ld{a.factors, a.coef + size_t(b) * a.coef_bstride, a.NC, a.ga, a.gd, a.n_factors, {}};
     LaneRec cur, nxt;
     ld.issue_factor(0);
@@ -139,6 +186,11 @@ __global__ __launch_bounds__(64) void k_lanes_fwd(PersistArgs a) {
                         q.y += k2r * ds.y + k2i * ds.x;
                     }
                 }
+            }
+            if (!FAST && pairs.n) {  // beta * (dense two-qubit terms)
+                const double2 pv = pairs.apply(v, lane);
+                q.x += br * pv.x - bi * pv.y;
+                q.y += br * pv.y + bi * pv.x;
             }
             v = q;
             const int save = __builtin_amdgcn_readlane(cur.save, fs);
@@ -219,6 +271,9 @@ __global__ __launch_bounds__(64) void k_lanes_bwd(PersistBwdArgs a) {
 #pragma unroll
     for (int g = 0; g < kPersistGroups; ++g) acc_re[g] = acc_im[g] = acc_det[g] = 0.0;
 
+    LanePairs pairs, pairs_adj;  // the blocks and their conjugate transposes (the generator need not be Hermitian)
+    pairs.load(a.pair, 0, lane);
+    pairs_adj.load(a.pair, 1, lane);
     LaneRecLoader ld{a.factors, a.coef + size_t(b) * a.coef_bstride, a.NC, a.ga, a.gd, a.n_factors, {}};
     LaneRec cur;
     int w0 = a.n_factors, w1 = -1;  // window [w0, w1] of factor indices held by lanes 0 .. w1 - w0
@@ -271,6 +326,11 @@ __global__ __launch_bounds__(64) void k_lanes_bwd(PersistBwdArgs a) {
                         q.y += k2r * ds.y + k2i * ds.x;
                     }
                 }
+            }
+            if (!FAST && pairs.n) {
+                const double2 pv = pairs.apply(v, lane);
+                q.x += br * pv.x - bi * pv.y;
+                q.y += br * pv.y + bi * pv.x;
             }
             return q;
         };
@@ -325,7 +385,12 @@ __global__ __launch_bounds__(64) void k_lanes_bwd(PersistBwdArgs a) {
                     acc_im[g] += br * z2i + bi * z2r;
                 }
             }
-            if (stage_end && a.want_tau) {  // dL/dtau = Im<mu, H x_out> = Im<H mu, x_out>
+            if (!FAST && pairs.n) {  // the generator is M = K + T with K Hermitian: M^dagger mu = K mu + T^dagger mu
+                const double2 pv = pairs_adj.apply(mu, lane);
+                hm.x += pv.x;
+                hm.y += pv.y;
+            }
+            if (stage_end && a.want_tau) {  // dL/dtau = Im<mu, M x_out> = Im<M^dagger mu, x_out>
                 const double2 o = (i == M - 1) ? xend : park[i * 64 + lane];
                 acc_tau += hm.x * o.y - hm.y * o.x;
             }

@@ -1538,7 +1538,7 @@ int launch_persist_t(const PersistArgs& pa, int B, hipStream_t stream) {
 
 template <int LT, bool CPLX>
 int launch_lanes_fwd_t(const PersistArgs& pa, int B, hipStream_t stream) {
-    if (pa.ga == 1 && pa.gd <= 1 && pa.amask[0] == (1u << LT) - 1u)
+    if (pa.ga == 1 && pa.gd <= 1 && pa.amask[0] == (1u << LT) - 1u && pa.pair.n == 0)
         hipLaunchKernelGGL((k_lanes_fwd<LT, CPLX, true>), dim3(B), dim3(64), 0, stream, pa);
     else
         hipLaunchKernelGGL((k_lanes_fwd<LT, CPLX, false>), dim3(B), dim3(64), 0, stream, pa);
@@ -1548,7 +1548,7 @@ int launch_lanes_fwd_t(const PersistArgs& pa, int B, hipStream_t stream) {
 
 // one amplitude per lane of one wave (lane_kernels.hpp); variant 8 keeps the LDS-tile kernels for A/B tests
 bool lanes_enabled(int N, int ga, int gd, int n_pair) {
-    return g_kernel_variant != 8 && N <= kLaneMaxQubits && n_pair == 0 && ga <= kPersistGroups && gd <= kPersistGroups;
+    return g_kernel_variant != 8 && N <= kLaneMaxQubits && n_pair <= kLanePairMax && ga <= kPersistGroups && gd <= kPersistGroups;
 }
 
 template <bool CPLX>
@@ -1592,7 +1592,7 @@ int launch_persist_bwd_t(const PersistBwdArgs& pa, int B, hipStream_t stream) {
 
 template <int LT, bool CPLX>
 int launch_lanes_bwd_t(const PersistBwdArgs& pa, int B, hipStream_t stream) {
-    if (pa.ga == 1 && pa.gd <= 1 && pa.amask[0] == (1u << LT) - 1u)
+    if (pa.ga == 1 && pa.gd <= 1 && pa.amask[0] == (1u << LT) - 1u && pa.pair.n == 0)
         hipLaunchKernelGGL((k_lanes_bwd<LT, CPLX, true>), dim3(B), dim3(64), 0, stream, pa);
     else
         hipLaunchKernelGGL((k_lanes_bwd<LT, CPLX, false>), dim3(B), dim3(64), 0, stream, pa);
