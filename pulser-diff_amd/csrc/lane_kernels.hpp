@@ -128,9 +128,11 @@ struct LaneRecLoader {
 // ---------------------------------------------------------------------------------------------------------------------
 // FAST: one amplitude group that drives every qubit (a global channel) and at most one detuning group — the usual
 // sequence: no group loops, no mask tests, no predicated coefficient broadcasts in the factor loop.
-template <int LT, bool CPLX, bool FAST>
+// GLMAX: group slots the generic (non-FAST) instantiation loops over: 2 when there are at most two amplitude and two detuning
+// groups (a doubled register of the master equation, one local channel next to the global one), else kPersistGroups.
+template <int LT, bool CPLX, bool FAST, int GLMAX = kPersistGroups>
 __global__ __launch_bounds__(64) void k_lanes_fwd(PersistArgs a) {
-    constexpr int GL = FAST ? 1 : kPersistGroups;
+    constexpr int GL = FAST ? 1 : GLMAX;
     constexpr int NT = 1 << LT;
     const unsigned lane = threadIdx.x;
     const bool active = lane < NT;
@@ -215,9 +217,9 @@ __global__ __launch_bounds__(64) void k_lanes_fwd(PersistArgs a) {
 //   Everything the NEXT interval needs from global memory (its start state, the cotangent weights of its end point) is
 //   requested while the current interval computes.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int LT, bool CPLX, bool FAST>
+template <int LT, bool CPLX, bool FAST, int GLMAX = kPersistGroups>
 __global__ __launch_bounds__(64) void k_lanes_bwd(PersistBwdArgs a) {
-    constexpr int GL = FAST ? 1 : kPersistGroups;
+    constexpr int GL = FAST ? 1 : GLMAX;
     constexpr int NT = 1 << LT;
     __shared__ __attribute__((aligned(16))) double2 park[(kLaneChunk - 1) * 64];
     const unsigned lane = threadIdx.x;

@@ -1540,6 +1540,8 @@ template <int LT, bool CPLX>
 int launch_lanes_fwd_t(const PersistArgs& pa, int B, hipStream_t stream) {
     if (pa.ga == 1 && pa.gd <= 1 && pa.amask[0] == (1u << LT) - 1u && pa.pair.n == 0)
         hipLaunchKernelGGL((k_lanes_fwd<LT, CPLX, true>), dim3(B), dim3(64), 0, stream, pa);
+    else if (pa.ga <= 2 && pa.gd <= 2)
+        hipLaunchKernelGGL((k_lanes_fwd<LT, CPLX, false, 2>), dim3(B), dim3(64), 0, stream, pa);
     else
         hipLaunchKernelGGL((k_lanes_fwd<LT, CPLX, false>), dim3(B), dim3(64), 0, stream, pa);
     LAUNCH_CHECK();
@@ -1594,6 +1596,8 @@ template <int LT, bool CPLX>
 int launch_lanes_bwd_t(const PersistBwdArgs& pa, int B, hipStream_t stream) {
     if (pa.ga == 1 && pa.gd <= 1 && pa.amask[0] == (1u << LT) - 1u && pa.pair.n == 0)
         hipLaunchKernelGGL((k_lanes_bwd<LT, CPLX, true>), dim3(B), dim3(64), 0, stream, pa);
+    else if (pa.ga <= 2 && pa.gd <= 2)
+        hipLaunchKernelGGL((k_lanes_bwd<LT, CPLX, false, 2>), dim3(B), dim3(64), 0, stream, pa);
     else
         hipLaunchKernelGGL((k_lanes_bwd<LT, CPLX, false>), dim3(B), dim3(64), 0, stream, pa);
     LAUNCH_CHECK();
