@@ -85,9 +85,10 @@ __device__ __forceinline__ void stage_factors(const PersistFactor* __restrict__ 
 // records come from the LDS stage; otherwise generic loops over up to kMaxGroups groups with coefficients from global.
 // FAST (implies SMALLG): one amplitude group driving every qubit (a global channel) and at most one detuning group — no
 // group loops, no mask tests.
-template <int LT, int LGT, bool CPLX, bool SMALLG, bool FAST = false>
+// GLMAX: group slots the SMALLG instantiation loops over (2 when there are at most two amplitude and two detuning groups).
+template <int LT, int LGT, bool CPLX, bool SMALLG, bool FAST = false, int GLMAX = kPersistGroups>
 __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist(PersistArgs a) {
-    constexpr int GL = FAST ? 1 : kPersistGroups;
+    constexpr int GL = FAST ? 1 : GLMAX;
     constexpr int NT = 1 << LGT, R = 1 << (LT - LGT), NTL = NT < 64 ? 64 : NT, NW = NTL / 64;
     __shared__ __attribute__((aligned(16))) double2 tile[1 << LT];
     __shared__ double red[NW];
@@ -275,9 +276,9 @@ struct PersistBwdArgs {
     PairArgs pair;
 };
 
-template <int LT, int LGT, bool CPLX, bool FAST = false>  // FAST: one global drive, at most one detuning group (as in k_persist)
+template <int LT, int LGT, bool CPLX, bool FAST = false, int GLMAX = kPersistGroups>  // FAST / GLMAX: as in k_persist
 __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist_bwd(PersistBwdArgs a) {
-    constexpr int GL = FAST ? 1 : kPersistGroups;
+    constexpr int GL = FAST ? 1 : GLMAX;
     constexpr int NT = 1 << LGT, R = 1 << (LT - LGT), NTL = NT < 64 ? 64 : NT, NW = NTL / 64;
     constexpr int NV = 3 * kPersistGroups + 1;
     constexpr int PARK = (1 << LT) <= kParkAmps ? kParkAmps : 1;   // parked factor inputs (amplitudes) in LDS

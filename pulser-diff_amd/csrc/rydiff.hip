@@ -1528,6 +1528,8 @@ int launch_persist_t(const PersistArgs& pa, int B, hipStream_t stream) {
     const dim3 block(LGT < 6 ? 64 : (1 << LGT));
     if (pa.ga == 1 && pa.gd <= 1 && pa.amask[0] == (1u << LT) - 1u && pa.pair.n == 0)
         hipLaunchKernelGGL((k_persist<LT, LGT, CPLX, true, true>), dim3(B), block, 0, stream, pa);
+    else if (pa.ga <= 2 && pa.gd <= 2)
+        hipLaunchKernelGGL((k_persist<LT, LGT, CPLX, true, false, 2>), dim3(B), block, 0, stream, pa);
     else if (pa.ga <= kPersistGroups && pa.gd <= kPersistGroups)
         hipLaunchKernelGGL((k_persist<LT, LGT, CPLX, true>), dim3(B), block, 0, stream, pa);
     else
@@ -1586,6 +1588,8 @@ int launch_persist_bwd_t(const PersistBwdArgs& pa, int B, hipStream_t stream) {
     constexpr int LGT = LT < 10 ? LT : 9;  // 1024+ amplitudes: 512 threads, so the accumulators stay in registers
     if (pa.ga == 1 && pa.gd <= 1 && pa.amask[0] == (1u << LT) - 1u && pa.pair.n == 0)
         hipLaunchKernelGGL((k_persist_bwd<LT, LGT, CPLX, true>), dim3(B), dim3(LGT < 6 ? 64 : (1 << LGT)), 0, stream, pa);
+    else if (pa.ga <= 2 && pa.gd <= 2)
+        hipLaunchKernelGGL((k_persist_bwd<LT, LGT, CPLX, false, 2>), dim3(B), dim3(LGT < 6 ? 64 : (1 << LGT)), 0, stream, pa);
     else
         hipLaunchKernelGGL((k_persist_bwd<LT, LGT, CPLX>), dim3(B), dim3(LGT < 6 ? 64 : (1 << LGT)), 0, stream, pa);
     LAUNCH_CHECK();
