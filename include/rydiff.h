@@ -122,8 +122,9 @@ typedef struct RydPlanInfo {
  *   need_tape      1: reserve room for the (n_tsave, B, 2^N) trajectory inside the workspace (caller passes
  *                        states_out == NULL but wants gradients);
  *                  2: FULL tape — the output of every factor pass is kept ((total_factors+1) states), so the adjoint
- *                        sweep recomputes nothing.  Sized for 288 GB of HBM: 156 GiB at N=20, T=1000.  Falls back to 1
- *                        where the chained tile kernels do not apply (N <= 12 or N > 28, or with pair terms).
+ *                        sweep recomputes nothing.  Sized for 288 GB of HBM: 156 GiB at N=20, T=1000.  Granted from 12
+ *                        qubits on and without pair terms (below, the adjoint sweep is one launch and recomputes on chip);
+ *                        otherwise falls back to 1.  RydPlanInfo.tape_mode reports what was granted.
  *   need_backward  != 0: reserve the backward-sweep buffers too
  *   scratch        DEVICE, >= RYDIFF_PLAN_SCRATCH_BYTES */
 int rydiff_plan(const RydProblem* p, int need_tape, int need_backward, void* scratch, void* stream, RydPlanInfo* info);
@@ -133,7 +134,9 @@ int rydiff_plan(const RydProblem* p, int need_tape, int need_backward, void* scr
  *   info        HOST: result of rydiff_plan for the SAME table values (no synchronisation then), or NULL to plan
  *               internally (one synchronisation; workspace must then be large enough, see RYDIFF_EWORKSPACE)
  *   psi0        DEVICE complex128 [B][2^N]
- *   states_out  DEVICE complex128 [n_tsave][B][2^N], or NULL (trajectory kept in the workspace tape if need_tape)
+ *   states_out  DEVICE complex128 [n_tsave][B][2^N], or NULL (trajectory kept in the workspace tape if need_tape).
+ *               With need_tape = 2 AND states_out the factor outputs go to the (granted) full tape and the states at the
+ *               save points are copied out of it — stored states plus a later gradient without recomputation.
  *   expect_out  DEVICE float64 [n_obs][n_tsave][B], or NULL */
 int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi0, void* states_out, double* expect_out,
                    void* workspace, size_t workspace_bytes, int need_tape, void* stream);
@@ -142,7 +145,8 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
  * sub-step (derivative.py:40,76).  Cotangents use torch's convention for complex tensors
  * (grad = dL/dRe + i dL/dIm).  The workspace must be the one the forward call used when the
  * trajectory lives in its tape (states == NULL).
- *   states       DEVICE: the states_out of the forward call, or NULL to use the workspace tape
+ *   states       DEVICE: the states_out of the forward call, or NULL to use the workspace tape (with need_tape = 2 the
+ *                granted full workspace tape is used even when states is given)
  *   grad_states  DEVICE complex128 [n_tsave][B][2^N] or NULL
  *   grad_expect  DEVICE float64 [n_obs][n_tsave][B] or NULL
  *   g_amp        DEVICE complex128 [coeff_batch][n_amp_terms][n_samples] or NULL   (overwritten)

@@ -1724,19 +1724,24 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!psi0) return fail(RYDIFF_EINVAL, "null psi0");
     Runtime rt;
-    int rc = prepare(p, info, workspace, workspace_bytes, states_out ? 0 : need_tape, false, stream, rt);
+    // need_tape = 2 together with states_out: the caller wants the stored states AND a gradient later — where the full tape is
+    // granted the factor outputs go to the workspace tape and the states at the save points are copied out of it
+    int rc = prepare(p, info, workspace, workspace_bytes, need_tape == 2 ? 2 : (states_out ? 0 : need_tape), false, stream, rt);
     if (rc) return rc;
     const Plan& pl = rt.pl;
     char* ws = static_cast<char*>(workspace);
     const size_t sv = size_t(pl.B) * pl.dim;  // complex elements per saved state
     double2* buf[2] = {reinterpret_cast<double2*>(ws + pl.off_buf0), reinterpret_cast<double2*>(ws + pl.off_buf1)};
-    double2* tape = states_out ? static_cast<double2*>(states_out)
-                               : (need_tape ? reinterpret_cast<double2*>(ws + pl.off_tape) : nullptr);
+    const bool full_ws_tape = pl.tape_mode == 2;  // (prepare downgrades the request where the full tape is not possible)
+    double2* sout = static_cast<double2*>(states_out);
+    double2* tape = (states_out && !full_ws_tape) ? sout : (pl.tape_mode ? reinterpret_cast<double2*>(ws + pl.off_tape) : nullptr);
+    double2* copy_out = (states_out && full_ws_tape) ? sout : nullptr;  // states at the save points, copied from the full tape
     const double2* cur = static_cast<const double2*>(psi0);
     if (tape) {
         HIP_TRY(hipMemcpyAsync(tape, psi0, pl.state_bytes, hipMemcpyDeviceToDevice, stream));
         cur = tape;
     }
+    if (copy_out) HIP_TRY(hipMemcpyAsync(copy_out, psi0, pl.state_bytes, hipMemcpyDeviceToDevice, stream));
     const double* obs = p->obs_diag;
     const bool want_exp = expect_out && pl.n_obs > 0;
     const unsigned red_blocks = unsigned(std::min<size_t>((pl.dim + 255) / 256, 1024));
@@ -1757,9 +1762,8 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
         HIP_TRY(hipStreamSynchronize(stream));
         PersistArgs pa{};
         pa.psi0 = static_cast<const double2*>(psi0);
-        const bool full = pl.tape_mode == 2 && !states_out && tape;
-        pa.states = full ? nullptr : tape;
-        pa.tape_all = full ? tape : nullptr;
+        pa.states = full_ws_tape ? copy_out : tape;
+        pa.tape_all = full_ws_tape ? tape : nullptr;
         pa.udiag = reinterpret_cast<const double*>(ws + pl.off_udiag);
         pa.coef = reinterpret_cast<const double*>(ws + pl.off_coef);
         pa.coef_bstride = pl.Bc > 1 ? long(pl.stages.size()) * pl.NC : 0;
@@ -1794,14 +1798,18 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
             }
         }
         int flip = 0;
-        const bool full_tape = (pl.tape_mode == 2) && !states_out;
+        const bool full_tape = full_ws_tape;
         auto dst = [&](int i) -> double2* {
             if (full_tape) return tape + size_t(i + 1) * sv;  // entry g = output of global factor g (entry 0 = psi0)
             if (step_of_end[i] && tape) return tape + size_t(step_of_end[i]) * sv;
             flip ^= 1;
             return buf[flip];
         };
-        auto done = [&](int, const double2*) -> int { return RYDIFF_OK; };
+        auto done = [&](int i, const double2* out) -> int {
+            if (copy_out && step_of_end[i])
+                HIP_TRY(hipMemcpyAsync(copy_out + size_t(step_of_end[i]) * sv, out, pl.state_bytes, hipMemcpyDeviceToDevice, stream));
+            return RYDIFF_OK;
+        };
         auto exp_slot = [&](int i, ChainStep& cs) {
             if (want_exp && step_of_end[i]) {  // the pass that completes a step's last factor also reduces <O>
                 cs.obs = obs;
@@ -1815,7 +1823,7 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
         return RYDIFF_OK;
     }
     int pp = 0;
-    const bool full_tape_direct = (pl.tape_mode == 2) && !states_out && tape;
+    const bool full_tape_direct = full_ws_tape && tape;
     size_t gfac = 0;  // global factor index: with the full tape entry g + 1 = output of factor g (entry 0 = psi0)
     for (int k = 0; k < pl.T; ++k) {
         build_step_chain(rt, k, chain);
@@ -1833,6 +1841,7 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
             if (rc) return rc;
             cur = dst;
         }
+        if (copy_out) HIP_TRY(hipMemcpyAsync(copy_out + size_t(k + 1) * sv, cur, pl.state_bytes, hipMemcpyDeviceToDevice, stream));
         if (want_exp) {
             hipLaunchKernelGGL(k_expect_diag, dim3(red_blocks, pl.B), dim3(256), 0, stream, cur, obs, expect_out, pl.n_obs, pl.T + 1, k + 1, pl.B, uint32_t(pl.dim));
             LAUNCH_CHECK();
@@ -1850,13 +1859,15 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!states && !need_tape) return fail(RYDIFF_EINVAL, "backward needs the trajectory: pass states or use the workspace tape");
     Runtime rt;
-    int rc = prepare(p, info, workspace, workspace_bytes, states ? 0 : need_tape, true, stream, rt);
+    int rc = prepare(p, info, workspace, workspace_bytes, need_tape == 2 ? 2 : (states ? 0 : need_tape), true, stream, rt);
     if (rc) return rc;
     const Plan& pl = rt.pl;
     char* ws = static_cast<char*>(workspace);
     const size_t sv = size_t(pl.B) * pl.dim;
     const size_t E = pl.stages.size();
-    const double2* tape = states ? static_cast<const double2*>(states) : reinterpret_cast<const double2*>(ws + pl.off_tape);
+    if (!states && !pl.tape_mode) return fail(RYDIFF_EINVAL, "backward needs the trajectory: pass states or use the workspace tape");
+    // the full workspace tape (written by a forward call with need_tape = 2) is preferred over `states`
+    const double2* tape = (pl.tape_mode == 2 || !states) ? reinterpret_cast<const double2*>(ws + pl.off_tape) : static_cast<const double2*>(states);
     double2* lam[2] = {reinterpret_cast<double2*>(ws + pl.off_buf0), reinterpret_cast<double2*>(ws + pl.off_buf1)};
     double2* chainbuf = reinterpret_cast<double2*>(ws + pl.off_chain);
     double* ge = reinterpret_cast<double*>(ws + pl.off_ge);
@@ -1875,7 +1886,7 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
     dim3 grid(unsigned((pl.dim + 255) / 256), pl.B);
     int cl = 0;
     // where the state at tsave[k] lives: one entry per tsave, or (full tape) one entry per factor pass
-    const bool full_tape = !states && pl.tape_mode == 2;
+    const bool full_tape = pl.tape_mode == 2;
     std::vector<int64_t> fprefix(pl.T + 1, 0);
     for (int k = 0; k < pl.T; ++k) {
         int64_t f = 0;

@@ -162,12 +162,14 @@ class _RydbergEvolve(torch.autograd.Function):
             scratch = torch.empty(_native.PLAN_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
             info = _native.RydPlanInfo()
             # with the trajectory kept in the workspace tape, size the workspace for the backward sweep right away
-            if need_tape and spec.tape in ("auto", "full"):
-                # FULL tape (every factor output kept, no recompute in the adjoint sweep) when HBM has room for it
+            if needs_grad and spec.tape in ("auto", "full"):
+                # FULL tape (every factor output kept, no recompute in the adjoint sweep) when HBM has room for it — also next
+                # to stored states (the states at the save points are then copied out of the tape), where it is granted
                 _native.check(L.rydiff_plan(ctypes.byref(call.problem), 2, 1, _ptr(scratch), stream, ctypes.byref(info)))
                 free_bytes, _total = torch.cuda.mem_get_info(dev)
                 reusable = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-                if spec.tape == "full" or info.workspace_bytes < 0.8 * (free_bytes + reusable):
+                fits = spec.tape == "full" or info.workspace_bytes < 0.8 * (free_bytes + reusable)
+                if fits and (need_tape or info.tape_mode == 2):
                     need_tape = 2
             if need_tape != 2:
                 _native.check(L.rydiff_plan(ctypes.byref(call.problem), need_tape, need_tape, _ptr(scratch),
