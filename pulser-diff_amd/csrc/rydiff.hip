@@ -481,9 +481,15 @@ __global__ __launch_bounds__(256) void k_factor_bwd_direct(FactorBwdArgs a) {
 // loop over the NQ bits is unrolled, so all partner loads are in flight together and the plain / signed partner sums replace
 // the per-bit branch (c*s1 + conj(c)*s0 = cr*(s1+s0) + i*ci*(s1-s0)).
 // ------------------------------------------------------------------------------------------------
-template <int NQ>
+// ONEXCD (12 and 13 qubits: <= 32 workgroups): the grid is 8x oversubscribed and only the workgroups that the round-robin dispatch
+// places on XCD (trajectory % 8) work, so that a trajectory's vectors stay in ONE XCD's L2 from pass to pass — the partner
+// loads then hit that L2 instead of crossing the fabric (placement is a speed matter only: results do not depend on it).
+// Measured forward steps/s with / without: N=13 39.7 k / 23.9 k, N=14 24.3 k / 22.0 k (but its adjoint 10 % slower), N=15 21.8 k /
+// 28.6 k, N=16 13.2 k / 24.6 k — one XCD's 32 CUs are not enough from 14 qubits on.
+template <int NQ, bool ONEXCD>
 __global__ __launch_bounds__(256) void k_factor_direct_global(FactorArgs a) {
-    const uint32_t x = blockIdx.x * 256u + threadIdx.x;  // dim = 2^NQ is a multiple of 256
+    if (ONEXCD && (blockIdx.x & 7u) != (blockIdx.y & 7u)) return;
+    const uint32_t x = (ONEXCD ? (blockIdx.x >> 3) : blockIdx.x) * 256u + threadIdx.x;  // dim = 2^NQ is a multiple of 256
     const size_t boff = size_t(blockIdx.y) * a.dim;
     const double2* __restrict__ xin = a.xin + boff;
     const double* __restrict__ cf = a.use_inline ? a.coef_inline : a.coef + blockIdx.y * a.coef_bstride;
@@ -508,15 +514,17 @@ __global__ __launch_bounds__(256) void k_factor_direct_global(FactorArgs a) {
     a.xout[boff + x] = make_double2(dr * v.x - di * v.y + a.br * fr - a.bi * fi, dr * v.y + di * v.x + a.br * fi + a.bi * fr);
 }
 
-template <int NQ>
+template <int NQ, bool ONEXCD>
 __global__ __launch_bounds__(256) void k_factor_bwd_direct_global(FactorBwdArgs a) {
     __shared__ double lds[8];
-    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    if (ONEXCD && (blockIdx.x & 7u) != (blockIdx.y & 7u)) return;
+    const uint32_t wg = ONEXCD ? (blockIdx.x >> 3) : blockIdx.x;
+    const uint32_t x = wg * 256u + threadIdx.x;
     const size_t boff = size_t(blockIdx.y) * a.dim;
     const double2* __restrict__ gin = a.gin + boff;
     const double2* __restrict__ xin = a.xin + boff;
     const double* __restrict__ cf = a.coef + blockIdx.y * a.coef_bstride;
-    double* __restrict__ ge = a.ge + blockIdx.y * a.ge_bstride + (blockIdx.x % kGradReplicas) * a.ge_rstride;
+    double* __restrict__ ge = a.ge + blockIdx.y * a.ge_bstride + (wg % kGradReplicas) * a.ge_rstride;
     double2 pg[NQ], px[NQ];
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
@@ -1078,10 +1086,14 @@ int launch_factor(const Runtime& rt, char* ws, const double2* xin, double2* xout
     fa.pair = rt.parg;
     dim3 grid(unsigned((pl.dim + 255) / 256), pl.B);
     if (direct_global_ok(pl)) {
+        const dim3 grid8(grid.x * 8, grid.y);  // ONEXCD instantiations: 8x oversubscribed grid
         switch (pl.N) {
-#define RYDIFF_CASE(NQ) case NQ: hipLaunchKernelGGL(k_factor_direct_global<NQ>, grid, dim3(256), 0, stream, fa); break;
-            RYDIFF_CASE(12) RYDIFF_CASE(13) RYDIFF_CASE(14) RYDIFF_CASE(15) RYDIFF_CASE(16) RYDIFF_CASE(17) RYDIFF_CASE(18) RYDIFF_CASE(19) RYDIFF_CASE(20)
+#define RYDIFF_CASE1(NQ) case NQ: hipLaunchKernelGGL((k_factor_direct_global<NQ, true>), grid8, dim3(256), 0, stream, fa); break;
+#define RYDIFF_CASE(NQ) case NQ: hipLaunchKernelGGL((k_factor_direct_global<NQ, false>), grid, dim3(256), 0, stream, fa); break;
+            RYDIFF_CASE1(12) RYDIFF_CASE1(13)  // one XCD has the CUs for <= 32 workgroups; beyond, spreading wins (measured)
+            RYDIFF_CASE(14) RYDIFF_CASE(15) RYDIFF_CASE(16) RYDIFF_CASE(17) RYDIFF_CASE(18) RYDIFF_CASE(19) RYDIFF_CASE(20)
 #undef RYDIFF_CASE
+#undef RYDIFF_CASE1
         }
     } else {
         hipLaunchKernelGGL(k_factor_direct, grid, dim3(256), 0, stream, fa);
@@ -2067,10 +2079,14 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
             ba.g = rt.garg;
             ba.pair = rt.parg;
             if (direct_global_ok(pl)) {
+                const dim3 grid8(grid.x * 8, grid.y);
                 switch (pl.N) {
-#define RYDIFF_CASE(NQ) case NQ: hipLaunchKernelGGL(k_factor_bwd_direct_global<NQ>, grid, dim3(256), 0, stream, ba); break;
-                    RYDIFF_CASE(12) RYDIFF_CASE(13) RYDIFF_CASE(14) RYDIFF_CASE(15) RYDIFF_CASE(16) RYDIFF_CASE(17) RYDIFF_CASE(18) RYDIFF_CASE(19) RYDIFF_CASE(20)
+#define RYDIFF_CASE1(NQ) case NQ: hipLaunchKernelGGL((k_factor_bwd_direct_global<NQ, true>), grid8, dim3(256), 0, stream, ba); break;
+#define RYDIFF_CASE(NQ) case NQ: hipLaunchKernelGGL((k_factor_bwd_direct_global<NQ, false>), grid, dim3(256), 0, stream, ba); break;
+                    RYDIFF_CASE1(12) RYDIFF_CASE1(13)
+                    RYDIFF_CASE(14) RYDIFF_CASE(15) RYDIFF_CASE(16) RYDIFF_CASE(17) RYDIFF_CASE(18) RYDIFF_CASE(19) RYDIFF_CASE(20)
 #undef RYDIFF_CASE
+#undef RYDIFF_CASE1
                 }
             } else {
                 hipLaunchKernelGGL(k_factor_bwd_direct, grid, dim3(256), 0, stream, ba);
