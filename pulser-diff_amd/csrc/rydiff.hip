@@ -117,6 +117,11 @@ struct FactorArgs {
     const double2* remote[kMaxRemote];
     double rc[2 * kMaxRemote];
     PairArgs pair;
+    // fused <y|O|y> of the vector this launch produces (k_factor_direct_global only; last factor of a time step)
+    const double* obs = nullptr;   // [n_obs][dim]
+    double* expect_slot = nullptr; // &expect_out[0][k][0]
+    int n_obs = 0;
+    long exp_ostride = 0;          // n_tsave * B
 };
 
 struct FactorBwdArgs {
@@ -511,7 +516,13 @@ __global__ __launch_bounds__(256) void k_factor_direct_global(FactorArgs a) {
     const double cr = cf[0], ci = cf[1];
     // F = cr*ts + i*ci*ds
     const double fr = cr * tsr - ci * dsi, fi = cr * tsi + ci * dsr;
-    a.xout[boff + x] = make_double2(dr * v.x - di * v.y + a.br * fr - a.bi * fi, dr * v.y + di * v.x + a.br * fi + a.bi * fr);
+    const double2 y = make_double2(dr * v.x - di * v.y + a.br * fr - a.bi * fi, dr * v.y + di * v.x + a.br * fi + a.bi * fr);
+    a.xout[boff + x] = y;
+    if (a.obs) {  // wave-uniform: <y|O|y> for diagonal observables straight from the register that holds y
+        __shared__ double lds[8];
+        const double w = y.x * y.x + y.y * y.y;
+        for (int o = 0; o < a.n_obs; ++o) block_atomic_add(a.obs[size_t(o) * a.dim + x] * w, a.expect_slot + o * a.exp_ostride + blockIdx.y, lds);
+    }
 }
 
 template <int NQ, bool ONEXCD>
@@ -1068,8 +1079,11 @@ bool direct_global_ok(const Plan& pl) {
            pl.ga.amp_index_mask[0] == (1u << pl.N) - 1u;
 }
 
-int launch_factor(const Runtime& rt, char* ws, const double2* xin, double2* xout, int stage, const FactorScalars& s, hipStream_t stream) {
+// obs / expect_slot: fuse <y|O|y> into this launch where the kernel can (returns *fused = true then)
+int launch_factor(const Runtime& rt, char* ws, const double2* xin, double2* xout, int stage, const FactorScalars& s, hipStream_t stream,
+                  const double* obs = nullptr, double* expect_slot = nullptr, bool* fused = nullptr) {
     const Plan& pl = rt.pl;
+    if (fused) *fused = false;
     if (single_pass_enabled(rt)) return launch_single_fwd(rt, ws, xin, xout, stage, s, stream);
     FactorArgs fa{};
     fa.xin = xin;
@@ -1086,6 +1100,13 @@ int launch_factor(const Runtime& rt, char* ws, const double2* xin, double2* xout
     fa.pair = rt.parg;
     dim3 grid(unsigned((pl.dim + 255) / 256), pl.B);
     if (direct_global_ok(pl)) {
+        if (obs && expect_slot) {
+            fa.obs = obs;
+            fa.expect_slot = expect_slot;
+            fa.n_obs = pl.n_obs;
+            fa.exp_ostride = long(pl.T + 1) * pl.B;
+            if (fused) *fused = true;
+        }
         const dim3 grid8(grid.x * 8, grid.y);  // ONEXCD instantiations: 8x oversubscribed grid
         switch (pl.N) {
 #define RYDIFF_CASE1(NQ) case NQ: hipLaunchKernelGGL((k_factor_direct_global<NQ, true>), grid8, dim3(256), 0, stream, fa); break;
@@ -1836,6 +1857,7 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
     }
     int pp = 0;
     const bool full_tape_direct = full_ws_tape && tape;
+    bool exp_fused = false;
     size_t gfac = 0;  // global factor index: with the full tape entry g + 1 = output of factor g (entry 0 = psi0)
     for (int k = 0; k < pl.T; ++k) {
         build_step_chain(rt, k, chain);
@@ -1849,12 +1871,14 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
                 if (dst == cur) dst = buf[pp ^ 1];
                 pp ^= 1;
             }
-            rc = launch_factor(rt, ws, cur, dst, chain[i].stage, chain[i].s, stream);
+            const bool want_here = want_exp && last;  // the launch that completes the step also reduces <O> where it can
+            rc = launch_factor(rt, ws, cur, dst, chain[i].stage, chain[i].s, stream, want_here ? obs : nullptr,
+                               want_here ? expect_out + size_t(k + 1) * pl.B : nullptr, &exp_fused);
             if (rc) return rc;
             cur = dst;
         }
         if (copy_out) HIP_TRY(hipMemcpyAsync(copy_out + size_t(k + 1) * sv, cur, pl.state_bytes, hipMemcpyDeviceToDevice, stream));
-        if (want_exp) {
+        if (want_exp && !exp_fused) {
             hipLaunchKernelGGL(k_expect_diag, dim3(red_blocks, pl.B), dim3(256), 0, stream, cur, obs, expect_out, pl.n_obs, pl.T + 1, k + 1, pl.B, uint32_t(pl.dim));
             LAUNCH_CHECK();
         }
