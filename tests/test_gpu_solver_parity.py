@@ -429,3 +429,32 @@ def test_unrolled_global_drive_direct_kernels_match_generic_ones(cuda_device, n_
     assert np.abs((got["expect"] - ref["expect"]).cpu().numpy()).max() < 1e-10
     for key in ("amp", "det", "u"):
         assert rel_err(got[key].cpu().numpy(), ref[key].cpu().numpy()) < 1e-10, key
+
+
+@pytest.mark.parametrize("n_qubits", [12, 14])
+def test_stored_states_keep_the_full_tape_for_the_gradient(cuda_device, n_qubits):
+    """store_states=True with a gradient to follow (the emulator's default): from 12 qubits on the forward pass also keeps the
+    full per-factor tape (states at the save points are copied out of it), so the adjoint sweep recomputes nothing.  States
+    and gradients equal those of the one-state-per-tsave run (tape='steps': stored states as the tape, recompute)."""
+    from pulser_diff_amd.solver import ProblemSpec, SolverType, evolve
+
+    terms = random_terms(n_qubits, 11, 0.002, seed=700 + n_qubits, local=True)
+    amp, det, u, spec0 = to_native(terms, cuda_device, SolverType.KRYLOV_SE)
+    tsave0 = torch.linspace(0, 0.018, 5, dtype=torch.float64)
+    gen = torch.Generator().manual_seed(n_qubits)
+    psi = torch.randn(1, 2**n_qubits, generator=gen, dtype=torch.complex128)
+    psi = (psi / psi.norm()).to(cuda_device)
+    obs = R.total_magnetization_diag(n_qubits)[None].to(cuda_device)
+    probe = torch.randn(2**n_qubits, generator=gen, dtype=torch.complex128).to(cuda_device)
+    out = {}
+    for mode in ("steps", "auto"):
+        spec = ProblemSpec(n_qubits, spec0.dt, spec0.n_samples, spec0.amp_masks, spec0.det_masks, solver=SolverType.KRYLOV_SE,
+                           store_states=True, tape=mode)
+        leaves = [amp.clone().requires_grad_(True), det.clone().requires_grad_(True), u.clone().requires_grad_(True),
+                  tsave0.clone().requires_grad_(True), psi.clone().requires_grad_(True)]
+        states, expect = evolve(*leaves, spec, obs)
+        assert spec.options["_last_stats"]["tape"] == ("none" if mode == "steps" else "full")
+        (expect[0, -1, 0] + 0.4 * expect[0, 2, 0] + ((states[1] + states[-1]) @ probe.conj()).real.sum()).backward()
+        out[mode] = [states.detach().cpu(), expect.detach().cpu()] + [l.grad.detach().cpu() for l in leaves]
+    for name, a, b in zip(("states", "expect", "amp", "det", "u", "tsave", "psi0"), out["steps"], out["auto"]):
+        assert rel_err(b.numpy(), a.numpy()) < 1e-11, name
