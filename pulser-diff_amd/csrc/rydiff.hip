@@ -528,6 +528,7 @@ __global__ __launch_bounds__(256) void k_factor_direct_global(FactorArgs a) {
 template <int NQ, bool ONEXCD>
 __global__ __launch_bounds__(256) void k_factor_bwd_direct_global(FactorBwdArgs a) {
     __shared__ double lds[8];
+    __shared__ double lds3[12];  // 3 values x 4 waves
     if (ONEXCD && (blockIdx.x & 7u) != (blockIdx.y & 7u)) return;
     const uint32_t wg = ONEXCD ? (blockIdx.x >> 3) : blockIdx.x;
     const uint32_t x = wg * 256u + threadIdx.x;
@@ -567,9 +568,21 @@ __global__ __launch_bounds__(256) void k_factor_bwd_direct_global(FactorBwdArgs 
     const double pr = a.br * gy.x + a.bi * gy.y, pi = a.bi * gy.x - a.br * gy.y;
     const double r = pr * xi.x - pi * xi.y;  // Re(beta conj(gy) xi)
     if (a.wtot) unsafeAtomicAdd(a.wtot + x, r);
-    block_atomic_add(pr * xsr - pi * xsi, ge, lds);
-    block_atomic_add(-(pr * xdi + pi * xdr), ge + 1, lds);
-    for (int q = 0; q < a.g.gd; ++q) block_atomic_add(r * double(a.g.dcnt[q] - __popc(x & a.g.dmask[q])), ge + 2 + q, lds);
+    // the two drive gradients and the first detuning gradient share ONE workgroup reduction (one pair of barriers)
+    double v0 = wave_sum(pr * xsr - pi * xsi), v1 = wave_sum(-(pr * xdi + pi * xdr));
+    double v2 = wave_sum(a.g.gd > 0 ? r * double(a.g.dcnt[0] - __popc(x & a.g.dmask[0])) : 0.0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        lds3[wave] = v0;
+        lds3[4 + wave] = v1;
+        lds3[8 + wave] = v2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const double sum = lds3[4 * threadIdx.x] + lds3[4 * threadIdx.x + 1] + lds3[4 * threadIdx.x + 2] + lds3[4 * threadIdx.x + 3];
+        if (threadIdx.x < 2 || a.g.gd > 0) unsafeAtomicAdd(ge + threadIdx.x, sum);
+    }
+    for (int q = 1; q < a.g.gd; ++q) block_atomic_add(r * double(a.g.dcnt[q] - __popc(x & a.g.dmask[q])), ge + 2 + q, lds);
 }
 
 // dL/dtau of one exponential:  Re< g, -i H x >  = Im( sum_x conj(g[x]) (H x)[x] )
