@@ -39,6 +39,14 @@
  * caller passes a workspace sized by rydiff_plan().  All work is enqueued on `stream`.
  * Functions return 0 on success, a negative RYDIFF_E* code otherwise; rydiff_last_error()
  * gives the message (thread-local).  The library never aborts.
+ *
+ * Threads and streams: the library keeps NO mutable process state besides the thread-local error string (and a
+ * mutex-protected cache of polynomial designs, which only saves host time).  Every choice that steers a call — including
+ * the kernel family (RydProblem.kernel_variant) — travels in the RydProblem, so concurrent calls from different threads on
+ * different streams with distinct workspaces are independent.  rydiff_forward / rydiff_backward given a RydPlanInfo are
+ * fully ASYNCHRONOUS: they only enqueue work (host-side metadata reaches the device as kernel arguments, never through
+ * pageable-memory copies) and never synchronise the stream.  rydiff_plan is the one call that waits: the spectral bounds it
+ * computes on the device decide the polynomial degree, i.e. how many launches the host has to enqueue.
  */
 #ifndef RYDIFF_H
 #define RYDIFF_H
@@ -99,6 +107,18 @@ typedef struct RydProblem {
      * When in addition every table entry is real (RydPlanInfo.flags bit 0 clear) the chained adjoint passes skip the signed
      * partner sums and the contractions for dL/dIm(amp); the imaginary parts of g_amp are then not computed (zero). */
     int32_t real_amp_grad;
+
+    /* Kernel family, 0 = automatic (what production callers pass).  Non-zero values force one implementation so that
+     * parity tests can compare the families with each other and with the oracle, and tuning scripts can time them:
+     *   1 direct (one amplitude per thread, global partner loads)       9 direct, always the generic kernels
+     *   2 / 3 / 4 LDS-tiled chained passes with 512 / 256 / 1024 threads per tile (13 <= N <= 28; two tile layouts up to
+     *             N = 22, three from N = 23)
+     *   7 automatic, but three tile layouts wherever they are legal (21 <= N <= 28)
+     *   8 automatic, but the LDS-tile persistent kernels also up to 6 qubits (instead of the one-wave lane kernels)
+     *  10 chained passes with trajectory-per-XCD placement forced (L2-resident trajectories)
+     * "automatic" takes the one-launch sweeps up to 12 qubits, the direct kernels while few tiles are in flight
+     * (B * 2^N <= 2^18) and the chained passes beyond.  Results do not depend on the variant beyond rounding. */
+    int32_t kernel_variant;
 } RydProblem;
 
 /* Result of rydiff_plan(): everything that depends on the VALUES in the coefficient tables. */
@@ -117,7 +137,7 @@ typedef struct RydPlanInfo {
 
 #define RYDIFF_PLAN_SCRATCH_BYTES 1024
 
-/* Inspect the coefficient tables (one tiny kernel + ONE stream synchronisation), bound the spectrum,
+/* Inspect the coefficient tables (one tiny kernel + ONE stream synchronisation — the only one in the library), bound the spectrum,
  * choose sub-steps and polynomial degree, and size the workspace.
  *   need_tape      1: reserve room for the (n_tsave, B, 2^N) trajectory inside the workspace (caller passes
  *                        states_out == NULL but wants gradients);
@@ -131,8 +151,9 @@ int rydiff_plan(const RydProblem* p, int need_tape, int need_backward, void* scr
 
 /* Forward: replaces sesolve(H_t, psi0, tsave, solver, options).states (backend.py:488-494,513-521)
  * and SimulationResults.expect for diagonal observables (simresults.py:81-129).
- *   info        HOST: result of rydiff_plan for the SAME table values (no synchronisation then), or NULL to plan
- *               internally (one synchronisation; workspace must then be large enough, see RYDIFF_EWORKSPACE)
+ *   info        HOST: result of rydiff_plan for the SAME table values (the call is then asynchronous: it enqueues and
+ *               returns), or NULL to plan internally (one synchronisation; workspace must then be large enough, see
+ *               RYDIFF_EWORKSPACE)
  *   psi0        DEVICE complex128 [B][2^N]
  *   states_out  DEVICE complex128 [n_tsave][B][2^N], or NULL (trajectory kept in the workspace tape if need_tape).
  *               With need_tape = 2 AND states_out the factor outputs go to the (granted) full tape and the states at the
@@ -179,15 +200,6 @@ int rydiff_apply_factor(const RydProblem* p, const double* c_amp_reim, const dou
 int rydiff_design_polynomial(double rho, double tol, int max_degree, int* degree, double* roots_reim,
                              double* p0_reim, double* max_err);
 
-/* Selects the kernel implementation: 0 = auto, 1 = direct (one amplitude per thread, global partner loads),
- * 2 / 3 / 4 = LDS-tiled chained passes with 512 / 256 / 1024 threads per tile (13 <= N <= 28; two tile layouts up to
- * N = 22, three from N = 23), 5 = single-pass tiles with partner-tile loads, 6 = sub-tile pipelined chain (N <= 22),
- * 7 = auto with three tile layouts wherever they are legal (21 <= N <= 28), 8 = auto with the LDS-tile persistent kernels
- * also up to 6 qubits (instead of the one-wave lane kernels), 9 = direct as 1 but always the generic kernels (without the
- * unrolled instantiations for one global drive on 12..20 qubits).  "auto" takes the one-launch sweeps up to 12 qubits, the direct
- * kernels while few tiles are in flight (B * 2^N <= 2^18 forward-only, 2^17 with gradients) and the chained passes beyond.
- * Used by parity tests to A/B the kernels against each other and by the tuning scripts. */
-int rydiff_set_kernel_variant(int variant);
 
 const char* rydiff_last_error(void);
 const char* rydiff_version(void);

@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes
 import os
 import subprocess
+import threading
 from pathlib import Path
 
 _CSRC = Path(__file__).resolve().parent / "csrc"
@@ -51,6 +52,7 @@ class RydProblem(ctypes.Structure):
         ("pair_qubits", ctypes.c_void_p),
         ("pair_tables", ctypes.c_void_p),
         ("real_amp_grad", ctypes.c_int32),
+        ("kernel_variant", ctypes.c_int32),
     ]
 
 
@@ -76,7 +78,6 @@ EXPORTS = (
     "rydiff_apply_hamiltonian",
     "rydiff_apply_factor",
     "rydiff_design_polynomial",
-    "rydiff_set_kernel_variant",
     "rydiff_last_error",
     "rydiff_version",
 )
@@ -117,8 +118,6 @@ def lib() -> ctypes.CDLL:
     L.rydiff_apply_factor.restype = i32
     L.rydiff_design_polynomial.argtypes = [dbl, dbl, i32, ctypes.POINTER(i32), vp, vp, ctypes.POINTER(dbl)]
     L.rydiff_design_polynomial.restype = i32
-    L.rydiff_set_kernel_variant.argtypes = [i32]
-    L.rydiff_set_kernel_variant.restype = i32
     L.rydiff_last_error.restype = ctypes.c_char_p
     L.rydiff_version.restype = ctypes.c_char_p
     _lib = L
@@ -157,5 +156,19 @@ def design_polynomial(rho: float, tol: float = 1e-13, max_degree: int = 120):
     return roots[: 2 * m].view(np.complex128).copy(), complex(p0[0], p0[1]), err.value
 
 
+# The kernel family travels in RydProblem.kernel_variant (include/rydiff.h); the C library keeps no such state.  For the
+# A/B parity tests and tuning scripts this module holds a PER-THREAD default that ``ProblemSpec.kernel_variant = None``
+# problems pick up — two threads can therefore run different variants concurrently.
+_KNOWN_VARIANTS = (0, 1, 2, 3, 4, 7, 8, 9, 10)
+_tls = threading.local()
+
+
 def set_kernel_variant(variant: int) -> None:
-    check(lib().rydiff_set_kernel_variant(int(variant)))
+    """Default kernel variant of problems built on THIS thread (0 = automatic)."""
+    if int(variant) not in _KNOWN_VARIANTS:
+        raise ValueError(f"kernel variant must be one of {_KNOWN_VARIANTS}, got {variant}")
+    _tls.variant = int(variant)
+
+
+def default_kernel_variant() -> int:
+    return getattr(_tls, "variant", 0)

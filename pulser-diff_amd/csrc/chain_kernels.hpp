@@ -67,10 +67,13 @@ struct ChainArgs {
     uint32_t sta_mask[kMaxGroups];     // per flip group: TILE-bit mask handled by the start stage
     uint32_t dmask[kMaxGroups];        // detuning groups: amplitude-INDEX masks
     int dcnt[kMaxGroups];
-    // single-pass mode (layout A only, has_p = 0): the flips of the index bits OUTSIDE the tile are taken from the
-    // partner tiles in global memory (L2 / Infinity Cache) during the start stage, so q_out is the complete factor output
-    uint32_t hi_mask[kMaxGroups];      // per flip group: amplitude-INDEX bits >= LT
-    int xcd_swizzle;                   // map consecutive tiles of one 2^(N-3) slab to workgroups that share an XCD (blockIdx % 8)
+    // Trajectory-per-XCD placement (speed only, results do not depend on it): workgroups are dispatched round-robin over the
+    // 8 XCDs (workgroup id % 8), each XCD has its own 4 MiB L2.  With xcd_place the grid is (8 * tiles_per_traj, ceil(B/8)):
+    // workgroup w of row y works on tile w / 8 of trajectory 8 y + w % 8, so that ALL tiles of one trajectory, in every
+    // layout, run on one XCD and its vectors stay in that L2 from pass to pass (no fabric traffic).  0: grid (tiles, B).
+    int xcd_place;
+    int b_first, b_count;              // this launch covers trajectories [b_first, b_first + b_count)
+    int resident;                      // plain loads / stores (lines stay in the XCD's L2) instead of streaming ones
     // backward (adjoint) mode only: u/p/v/q are cotangents, gamma/beta above are already conjugated
     const double2* x_fin;   // input of the factor being finished (own elements only)
     const double2* x_sta;   // input of the factor being started
@@ -79,6 +82,14 @@ struct ChainArgs {
     long ge_bstride, ge_rstride;
     double cb_fin_r, cb_fin_i, cb_sta_r, cb_sta_i;  // un-conjugated beta of the two factors (contraction weights)
     double* wtot;           // optional U_ij-gradient accumulator [dim]
+    // fused cotangent injection (adjoint mode): the vector the finish stage completes is the cotangent at a save point k whose
+    // state is x_fin; add  grad_states[k] + 2 sum_o grad_expect[o][k][b] obs[o][x] x_fin[x]  (replaces k_inject launches and the
+    // host-side decision whether one is needed)
+    const double2* inj_gstate;  // grad_states[k] ([B][dim]) or nullptr
+    const double* inj_gexp;     // &grad_expect[0][k][0] or nullptr
+    const double* inj_obs;      // [n_obs][dim]
+    int inj_n_obs;
+    long inj_ostride;           // n_tsave * B
     // fused expectation values of the COMPLETE vector produced by the finish stage (forward mode, step ends)
     const double* obs;      // [n_obs][dim] or nullptr
     double* expect_slot;    // &expect_out[0][k][0]
@@ -257,7 +268,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     if (BWD) {
         for (int s = int(threadIdx.x); s < n_slots * NW; s += NT) red[s] = 0.0;  // published by the barrier after the tile write
     }
-    auto flush_gradients = [&](double* ge_fin_, double* ge_sta_) {
+    auto flush_gradients = [&](double* ge_fin_, double* ge_sta_) {  // (placed after the early exit of ragged groups: uniform per workgroup)
         __syncthreads();
         for (int s = int(threadIdx.x); s < n_slots; s += NT) {
             double sum = 0.0;
@@ -271,11 +282,16 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
         }
     };
     const unsigned tid = threadIdx.x;
-    // XCD-aware tile order (speed only): workgroups b and b+8 share an XCD's L2, so give each XCD a contiguous block of
-    // tiles — the partner tiles of the low tile-index bits are then hits in that L2
-    const unsigned ntile = gridDim.x;
-    const unsigned t = a.xcd_swizzle ? ((blockIdx.x & 7u) * (ntile >> 3) + (blockIdx.x >> 3)) : blockIdx.x;
-    const size_t boff = size_t(blockIdx.y) * a.dim;
+    const unsigned t = a.xcd_place ? (blockIdx.x >> 3) : blockIdx.x;                       // tile of the trajectory
+    const unsigned bl = a.xcd_place ? (blockIdx.y * 8u + (blockIdx.x & 7u)) : blockIdx.y;  // trajectory within the launch
+    if (bl >= unsigned(a.b_count)) return;                                                 // ragged last row of 8
+    const unsigned bt = unsigned(a.b_first) + bl;                                          // trajectory
+    const size_t boff = size_t(bt) * a.dim;
+    auto ld = [&](const double2* p) -> double2 { return a.resident ? *p : stream_load(p); };
+    auto st = [&](double2* p, const double2& v) {
+        if (a.resident) *p = v;
+        else stream_store(p, v);
+    };
     const unsigned lomask = (1u << a.lo) - 1u;
     const int midlow = a.hs - a.lo;
     const unsigned xbase = ((t & ((1u << midlow) - 1u)) << a.lo) | ((t >> midlow) << (a.hs + a.hb));
@@ -291,11 +307,11 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     for (int r = 0; r < R; ++r) {
         const unsigned i = unsigned(r) * NT + tid;
         xg[r] = xbase | (i & lomask) | ((i >> a.lo) << a.hs);
-        uu[r] = stream_load(a.u + boff + xg[r]);
+        uu[r] = ld(a.u + boff + xg[r]);
     }
     if (a.has_p) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = stream_load(a.p + boff + xg[r]);
+        for (int r = 0; r < R; ++r) acc[r] = ld(a.p + boff + xg[r]);
     }
     double dg[R];  // tile-local part of the interaction diagonal (32 KiB table shared by all tiles: L2-resident)
     if (a.has_q) {
@@ -322,13 +338,13 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     double* ge_fin = nullptr;
     double* ge_sta = nullptr;
     if (BWD) {
-        const long goff = blockIdx.y * a.ge_bstride + (blockIdx.x % kGradReplicas) * a.ge_rstride;
+        const long goff = bt * a.ge_bstride + (blockIdx.x % kGradReplicas) * a.ge_rstride;
         ge_fin = a.ge_fin + goff;
         ge_sta = a.ge_sta + goff;
     }
 
     if (a.has_p) {
-        const double* __restrict__ cf = a.coef_fin + blockIdx.y * a.coef_bstride;
+        const double* __restrict__ cf = a.coef_fin + bt * a.coef_bstride;
         for (int g = 0; g < GA; ++g) {
             const uint32_t mask = a.fin_mask[g];
             if (!mask) continue;
@@ -376,6 +392,29 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = uu[r];
     }
+    if (BWD && a.has_p && (a.inj_gexp || a.inj_gstate)) {  // wave-uniform: the completed cotangent sits at a save point
+        if (a.inj_gexp) {
+            bool any = false;
+            for (int o = 0; o < a.inj_n_obs; ++o) any |= a.inj_gexp[o * a.inj_ostride + bt] != 0.0;
+            if (any) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    double wsum = 0.0;
+                    for (int o = 0; o < a.inj_n_obs; ++o) wsum += a.inj_gexp[o * a.inj_ostride + bt] * a.inj_obs[size_t(o) * a.dim + xg[r]];
+                    acc[r].x += 2.0 * wsum * xf[r].x;
+                    acc[r].y += 2.0 * wsum * xf[r].y;
+                }
+            }
+        }
+        if (a.inj_gstate) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double2 gs = stream_load(a.inj_gstate + boff + xg[r]);
+                acc[r].x += gs.x;
+                acc[r].y += gs.y;
+            }
+        }
+    }
     if (BWD && !XS_EARLY && a.has_q) {  // issued here (not at the top) to stay inside the register budget of 1024-thread tiles
 #pragma unroll
         for (int r = 0; r < R; ++r) xs[r] = stream_load(a.x_sta + boff + xg[r]);
@@ -383,7 +422,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     RYDIFF_TL(2);
     if (a.write_v) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) stream_store(a.v_out + boff + xg[r], acc[r]);
+        for (int r = 0; r < R; ++r) st(a.v_out + boff + xg[r], acc[r]);
     }
     RYDIFF_TL(3);
     if (!BWD && a.obs) {  // <v|O|v> for diagonal observables, straight from the registers that hold v
@@ -391,7 +430,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
             double e = 0.0;
 #pragma unroll
             for (int r = 0; r < R; ++r) e += a.obs[size_t(o) * a.dim + xg[r]] * (acc[r].x * acc[r].x + acc[r].y * acc[r].y);
-            wg_atomic_add<NT>(e, a.expect_slot + o * a.exp_ostride + blockIdx.y, red);
+            wg_atomic_add<NT>(e, a.expect_slot + o * a.exp_ostride + bt, red);
         }
     }
     if (!a.has_q) {
@@ -407,7 +446,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
 #endif
     RYDIFF_TL(4);
 
-    const double* __restrict__ cf = a.coef_sta + blockIdx.y * a.coef_bstride;
+    const double* __restrict__ cf = a.coef_sta + bt * a.coef_bstride;
     // interaction diagonal: remote part of this tile + cross terms of the tile bits that are in |r> (n = 1 - bit)
     double vloc[LT];
     const double* __restrict__ vrow = a.vr + size_t(t) * 16;
@@ -456,31 +495,13 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     }
     for (int g = 0; g < GA; ++g) {
         const uint32_t mask = a.sta_mask[g];
-        if (!FAST && !mask && !a.hi_mask[g]) continue;
+        if (!FAST && !mask) continue;
         double2 ts[R], ds[R];
 #ifndef RYDIFF_ABLATE_COMPUTE
         partner_sums<LT, LGT, CPLX, FAST>(tile, acc, mask, tid, ts, ds);
 #else
         for (int r = 0; r < R; ++r) { ts[r] = acc[r]; ds[r] = acc[r]; }
 #endif
-        {   // single-pass mode: partner tiles for the index bits outside this tile (coalesced 16-B loads, same offsets)
-            uint32_t hm = FAST ? 0u : a.hi_mask[g];
-            while (hm) {
-                const uint32_t bit = hm & (0u - hm);
-                hm ^= bit;
-                const double sgn = (xbase & bit) ? 1.0 : -1.0;  // own bit of this whole tile
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const double2 pv = a.u[boff + (xg[r] ^ bit)];
-                    ts[r].x += pv.x;
-                    ts[r].y += pv.y;
-                    if (CPLX) {
-                        ds[r].x = fma(sgn, pv.x, ds[r].x);
-                        ds[r].y = fma(sgn, pv.y, ds[r].y);
-                    }
-                }
-            }
-        }
 #ifdef RYDIFF_ABLATE_COEF
         const double cr = a.sg_r, ci = a.sg_i;
 #else
@@ -515,7 +536,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     }
     RYDIFF_TL(5);
 #pragma unroll
-    for (int r = 0; r < R; ++r) stream_store(a.q_out + boff + xg[r], q[r]);
+    for (int r = 0; r < R; ++r) st(a.q_out + boff + xg[r], q[r]);
     if (BWD) flush_gradients(ge_fin, ge_sta);
     RYDIFF_TL(6);
 #ifdef RYDIFF_TIMELINE

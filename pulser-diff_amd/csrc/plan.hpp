@@ -60,8 +60,9 @@ struct Plan {
     size_t off_pair = 0;
 
     // workspace offsets (bytes)
-    size_t off_meta_idx = 0, off_meta_w = 0, off_coef = 0, off_stats = 0, off_udiag = 0, off_buf0 = 0, off_buf1 = 0;
+    size_t off_meta_idx = 0, off_coef = 0, off_stats = 0, off_udiag = 0, off_buf0 = 0, off_buf1 = 0;
     size_t off_tape = 0, off_chain = 0, off_ge = 0, off_wtot = 0, off_members = 0, off_meta2 = 0, off_pp0 = 0, off_pp1 = 0, off_split = 0, off_ptable = 0, ptable_bytes = 0;
+    size_t off_pm_begin = 0, off_pm_first = 0, off_pm_tau = 0, off_pm_nsub = 0;  // inputs of the on-device factor table build
     size_t state_bytes = 0;  // B * dim * 16
     size_t total_fwd = 0;
     int chain_slots = 0;
@@ -115,6 +116,10 @@ inline bool build_plan(const RydProblem* p, Plan& pl, std::string& err, double w
     }
     if (p->batch < 1 || (p->coeff_batch != 1 && p->coeff_batch != p->batch)) {
         err = "coeff_batch must be 1 or batch";
+        return false;
+    }
+    if (p->batch > 65535) {  // the trajectory index is the y dimension of every launch grid
+        err = "batch must be <= 65535 (split the columns / trajectories into several calls)";
         return false;
     }
     if (p->n_tsave < 2 || !p->tsave) {
@@ -319,8 +324,7 @@ inline size_t carve(Plan& pl, int tape_mode, bool need_backward, int chain_slots
         return o;
     };
     pl.off_stats = take(64 * sizeof(double));
-    pl.off_meta_idx = take(E * 4 * sizeof(int32_t));
-    pl.off_meta_w = take(E * 4 * sizeof(double));
+    pl.off_meta_idx = take(E * 24);  // StageDev records (rydiff.hip)
     pl.off_members = take(2 * kMaxGroups * sizeof(uint64_t));
     pl.off_coef = take(size_t(pl.Bc) * E * std::max(pl.NC, 1) * sizeof(double));
     pl.off_udiag = take(pl.dim * sizeof(double));
@@ -331,6 +335,12 @@ inline size_t carve(Plan& pl, int tape_mode, bool need_backward, int chain_slots
     // split interaction diagonal for the two tile layouts: utt[2][4096] + vr[2][tiles][16]
     pl.off_split = take(3 * (4096 + (pl.dim >> 11 ? (pl.dim >> 11) : 1) * 16) * sizeof(double));  // up to three tile layouts
     pl.off_ptable = take(pl.ptable_bytes);
+    if (pl.ptable_bytes) {
+        pl.off_pm_begin = take(size_t(pl.T + 1) * sizeof(int32_t));
+        pl.off_pm_first = take(size_t(pl.T + 1) * sizeof(int32_t));
+        pl.off_pm_tau = take(E * sizeof(double));
+        pl.off_pm_nsub = take(E * sizeof(int32_t));
+    }
     pl.off_pair = take(size_t(pl.n_pair) * 64 * sizeof(double));
     pl.total_fwd = off;
     pl.tape_mode = tape_mode;
@@ -341,7 +351,7 @@ inline size_t carve(Plan& pl, int tape_mode, bool need_backward, int chain_slots
         pl.off_chain = take(size_t(chain_slots > 0 ? chain_slots : 1) * pl.state_bytes);
         pl.off_ge = take(size_t(pl.Bc) * E * 64 /* kGradReplicas */ * (pl.NC + 1) * sizeof(double));
         pl.off_wtot = take(pl.dim * sizeof(double));
-        pl.off_meta2 = take(align_up(E * 4 * sizeof(double)) + align_up(E * 4 * sizeof(int32_t)) + align_up(E * 3 * sizeof(double)));
+        pl.off_meta2 = take(std::max(E * 40, size_t(pl.T + 1) * sizeof(int32_t)));  // StageBwdDev records, or the save-point flags of the one-launch adjoint
     }
     return off;
 }

@@ -15,9 +15,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <complex>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <type_traits>
 #include <string>
@@ -36,9 +38,7 @@ using namespace rydiff;
 constexpr int kGradReplicas = 64;
 constexpr int kMaxRemote = 6;  // up to 2^6 GPUs in a state-sharded run
 
-static thread_local std::string g_last_error;
-static int g_kernel_variant = 0;
-static int g_generic_direct = 0;  // kernel variant 9: direct kernels WITHOUT the unrolled global-drive instantiations (A/B reference)
+static thread_local std::string g_last_error;  // the only mutable per-thread state (include/rydiff.h: rydiff_last_error)
 #ifndef RYDIFF_TILE_BITS
 #define RYDIFF_TILE_BITS 12
 #endif
@@ -139,7 +139,37 @@ struct FactorBwdArgs {
     double gr, gi, br, bi;
     GroupArgs g;
     PairArgs pair;
+    // Fused cotangent injection (replaces a separate k_inject launch and the host-side decision whether one is needed):
+    // when gout is the cotangent at a save point k — xin is then the state there — add
+    //   grad_states[k][b][x] + 2 * sum_o grad_expect[o][k][b] * obs[o][x] * xin[x]
+    const double2* inj_gstate = nullptr;  // grad_states[k] ([B][dim]) or nullptr
+    const double* inj_gexp = nullptr;     // &grad_expect[0][k][0] or nullptr
+    const double* inj_obs = nullptr;      // [n_obs][dim]
+    int inj_n_obs = 0;
+    long inj_ostride = 0;                 // n_tsave * B
 };
+
+// the injected cotangent at amplitude x of trajectory b (see FactorBwdArgs); wave-uniform control flow
+__device__ __forceinline__ double2 injected_cotangent(const double2* inj_gstate, const double* inj_gexp, const double* inj_obs,
+                                                      int n_obs, long ostride, uint32_t dim, int b, size_t boff, uint32_t x,
+                                                      const double2& psi) {
+    double2 add = make_double2(0.0, 0.0);
+    if (inj_gexp) {
+        double wsum = 0.0;
+        for (int o = 0; o < n_obs; ++o) {
+            const double ge = inj_gexp[o * ostride + b];
+            if (ge != 0.0) wsum += ge * inj_obs[size_t(o) * dim + x];
+        }
+        add.x = 2.0 * wsum * psi.x;
+        add.y = 2.0 * wsum * psi.y;
+    }
+    if (inj_gstate) {
+        const double2 g = inj_gstate[boff + x];
+        add.x += g.x;
+        add.y += g.y;
+    }
+    return add;
+}
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -244,7 +274,9 @@ __global__ void k_ugrad(double* __restrict__ g_u, const double* __restrict__ wto
 // table statistics for the spectral bound (over sample index i, all trajectories):
 //   stats[0] = max_i sum_g |c_g[i]| * count_g         (norm of the flip part, exact for commuting single-qubit terms)
 //   stats[1] = max_i sum_g max(+dcoef_g[i],0)*count_g  stats[2] = max_i sum_g max(-dcoef_g[i],0)*count_g
-//   stats[3] = sum of U_ij
+//   stats[3] = sum of max(U_ij, 0)     stats[5] = sum of max(-U_ij, 0)   (the doubled register of the master-equation path
+//                                                                        carries -U_ij on its column qubits)
+//   stats[4] = max_i sum_g |Im c_g[i]|   (non-zero: some drive has a phase)
 // all non-negative doubles -> their bit patterns order like unsigned integers (atomicMax on u64).
 // ------------------------------------------------------------------------------------------------
 struct StatsArgs {
@@ -286,9 +318,14 @@ __global__ void k_table_stats(unsigned long long* __restrict__ stats, StatsArgs 
         atomicMax(stats + 4, (unsigned long long)__double_as_longlong(imabs));
     }
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        double s = 0.0;
-        for (int k = 0; k < a.n_pairs; ++k) s += fabs(a.u_pairs[k]);
-        stats[3] = (unsigned long long)__double_as_longlong(s);
+        double sp = 0.0, sn = 0.0;
+        for (int k = 0; k < a.n_pairs; ++k) {
+            const double u = a.u_pairs[k];
+            if (u > 0.0) sp += u;
+            else sn -= u;
+        }
+        stats[3] = (unsigned long long)__double_as_longlong(sp);
+        stats[5] = (unsigned long long)__double_as_longlong(sn);
     }
 }
 
@@ -297,11 +334,21 @@ __global__ void k_table_stats(unsigned long long* __restrict__ stats, StatsArgs 
 //   c_g   = sum_{terms k in group g} sum_q w[e][q] * amp_k[idx[e][q]]        (hamiltonian.py:542)
 //   dcoef = 2 * sum_{terms k in group g} sum_q w[e][q] * det_k[idx[e][q]]    (hamiltonian.py:538-540)
 // ------------------------------------------------------------------------------------------------
+// per-exponential metadata as it lives on the device (uploaded through kernel arguments, see upload_words)
+struct StageDev {     // forward: the two samples entering the coefficient combination and their weights (hamiltonian.py:532-542)
+    double w0, w1;
+    int32_t i0, i1;
+};
+struct StageBwdDev {  // backward: how the exponential's duration and interpolation time depend on tsave
+    double tau_scale, tnw0, tnw1;
+    int32_t tn0, tn1, t_hi, t_lo;  // -1: not a tsave point
+};
+static_assert(sizeof(StageDev) == 24 && sizeof(StageBwdDev) == 40, "stage records are uploaded as 8-byte words");
+
 struct ExpandArgs {
     const double2* amp;
     const double* det;
-    const int32_t* idx;  // [E][4]
-    const double* w;     // [E][4]
+    const StageDev* st;  // [E]
     double* coef;        // [Bc][E][NC]
     int E, n_samples, Ka, Kd, NC, ga, gd;
     uint64_t amem[kMaxGroups], dmem[kMaxGroups];
@@ -312,20 +359,16 @@ __global__ void k_expand_coeffs(ExpandArgs a) {
     const int b = blockIdx.y;
     if (e >= a.E) return;
     double* rec = a.coef + (size_t(b) * a.E + e) * a.NC;
-    int idx[4];
-    double w[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        idx[q] = a.idx[e * 4 + q];
-        w[q] = a.w[e * 4 + q];
-    }
+    const StageDev sd = a.st[e];
+    const int idx[2] = {sd.i0, sd.i1};
+    const double w[2] = {sd.w0, sd.w1};
     for (int g = 0; g < a.ga; ++g) {
         double re = 0.0, im = 0.0;
         for (int k = 0; k < a.Ka; ++k)
             if (a.amem[g] >> k & 1ull) {
                 const double2* t = a.amp + (size_t(b) * a.Ka + k) * a.n_samples;
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < 2; ++q)
                     if (w[q] != 0.0) {
                         re += w[q] * t[idx[q]].x;
                         im += w[q] * t[idx[q]].y;
@@ -340,7 +383,7 @@ __global__ void k_expand_coeffs(ExpandArgs a) {
             if (a.dmem[g] >> k & 1ull) {
                 const double* t = a.det + (size_t(b) * a.Kd + k) * a.n_samples;
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < 2; ++q)
                     if (w[q] != 0.0) d += w[q] * t[idx[q]];
             }
         rec[2 * a.ga + g] = 2.0 * d;
@@ -476,6 +519,11 @@ __global__ __launch_bounds__(256) void k_factor_bwd_direct(FactorBwdArgs a) {
         ar += a.br * pv.x + a.bi * pv.y;
         ai += a.br * pv.y - a.bi * pv.x;
     }
+    if ((a.inj_gexp || a.inj_gstate) && live) {
+        const double2 add = injected_cotangent(a.inj_gstate, a.inj_gexp, a.inj_obs, a.inj_n_obs, a.inj_ostride, a.dim, blockIdx.y, boff, x, xi);
+        ar += add.x;
+        ai += add.y;
+    }
     if (live) a.gout[boff + x] = make_double2(ar, ai);
 }
 
@@ -563,7 +611,13 @@ __global__ __launch_bounds__(256) void k_factor_bwd_direct_global(FactorBwdArgs 
     // adjoint matvec: conj(gamma + beta d) gy + conj(beta) (cr*gs + i*ci*gd)
     const double dr = a.gr + a.br * d, di = -(a.gi + a.bi * d);
     const double fr = cr * gsr - ci * gdi, fi = cr * gsi + ci * gdr;
-    a.gout[boff + x] = make_double2(dr * gy.x - di * gy.y + a.br * fr + a.bi * fi, dr * gy.y + di * gy.x + a.br * fi - a.bi * fr);
+    double2 go = make_double2(dr * gy.x - di * gy.y + a.br * fr + a.bi * fi, dr * gy.y + di * gy.x + a.br * fi - a.bi * fr);
+    if (a.inj_gexp || a.inj_gstate) {
+        const double2 add = injected_cotangent(a.inj_gstate, a.inj_gexp, a.inj_obs, a.inj_n_obs, a.inj_ostride, a.dim, blockIdx.y, boff, x, xi);
+        go.x += add.x;
+        go.y += add.y;
+    }
+    a.gout[boff + x] = go;
     // contractions with a_ = beta * conj(gy):  dL/dRe c = Re(a_ * xs),  dL/dIm c = -Im(a_ * xd)
     const double pr = a.br * gy.x + a.bi * gy.y, pi = a.bi * gy.x - a.br * gy.y;
     const double r = pr * xi.x - pi * xi.y;  // Re(beta conj(gy) xi)
@@ -596,6 +650,7 @@ struct DotHArgs {
     long out_bstride;
     long out_rstride;
     uint32_t dim;
+    int b_first;  // the grid's y dimension covers trajectories b_first, b_first + 1, ...
     GroupArgs gr;
     PairArgs pair;
 };
@@ -605,9 +660,10 @@ __global__ __launch_bounds__(256) void k_dot_hx(DotHArgs a) {
     const uint32_t x = blockIdx.x * 256u + threadIdx.x;
     const bool live = x < a.dim;
     const uint32_t xs = live ? x : 0u;
-    const size_t boff = size_t(blockIdx.y) * a.dim;
+    const int bt = a.b_first + int(blockIdx.y);
+    const size_t boff = size_t(bt) * a.dim;
     const double2* __restrict__ xin = a.x + boff;
-    const double* __restrict__ cf = a.coef + blockIdx.y * a.coef_bstride;
+    const double* __restrict__ cf = a.coef + bt * a.coef_bstride;
     const double d = diag_value(a.udiag, cf, a.gr, xs);
     const double2 v = xin[xs];
     double hr = d * v.x, hi = d * v.y;
@@ -632,7 +688,7 @@ __global__ __launch_bounds__(256) void k_dot_hx(DotHArgs a) {
     const double2 g = (a.g + boff)[xs];
     // Im(conj(g) * h) = g.x*hi - g.y*hr
     const double val = live ? (g.x * hi - g.y * hr) : 0.0;
-    block_atomic_add(val, a.out + blockIdx.y * a.out_bstride + (blockIdx.x % kGradReplicas) * a.out_rstride, lds);
+    block_atomic_add(val, a.out + bt * a.out_bstride + (blockIdx.x % kGradReplicas) * a.out_rstride, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -698,11 +754,9 @@ __global__ void k_cotangent_flags(const double* __restrict__ gexp, int n_obs, in
 // ------------------------------------------------------------------------------------------------
 struct ScatterArgs {
     const double* ge;       // [Bc][E][kGradReplicas][NC+1]
-    const int32_t* idx;     // [E][4]
-    const double* w;        // [E][4]
-    const double* dwdt;     // [E][4]
-    const int32_t* tinfo;   // [E][4] = tn0, tn1, t_hi, t_lo  (-1: not a tsave point)
-    const double* tscale;   // [E][3] = tau_scale, tnw0, tnw1
+    const StageDev* st;     // [E]
+    const StageBwdDev* sb;  // [E] (only read when g_tsave)
+    double inv_dt;          // d w1 / d t = -d w0 / d t = 1/dt   (hamiltonian.py:538,542)
     const double2* amp;     // tables (for d coef / d t)
     const double* det;
     double2* g_amp;
@@ -724,6 +778,10 @@ __global__ void k_scatter_grads(ScatterArgs a) {
         rec[c] = sum;
     }
     double dLdt = 0.0;
+    const StageDev sd = a.st[e];
+    const double wq[2] = {sd.w0, sd.w1};
+    const int iq[2] = {sd.i0, sd.i1};
+    const double dwq[2] = {a.g_tsave ? -a.inv_dt : 0.0, a.g_tsave ? a.inv_dt : 0.0};
     for (int k = 0; k < a.Ka; ++k) {
         double gr = 0.0, gi = 0.0;
         for (int g = 0; g < a.ga; ++g)
@@ -732,9 +790,9 @@ __global__ void k_scatter_grads(ScatterArgs a) {
                 gi += rec[a.ga + g];
             }
         const double2* t = a.amp + (size_t(b) * a.Ka + k) * a.n_samples;
-        for (int q = 0; q < 4; ++q) {
-            const double w = a.w[e * 4 + q], dw = a.dwdt[e * 4 + q];
-            const int i = a.idx[e * 4 + q];
+        for (int q = 0; q < 2; ++q) {
+            const double w = wq[q], dw = dwq[q];
+            const int i = iq[q];
             if (a.g_amp && w != 0.0) {
                 double* dst = reinterpret_cast<double*>(a.g_amp + (size_t(b) * a.Ka + k) * a.n_samples + i);
                 unsafeAtomicAdd(dst, w * gr);
@@ -748,20 +806,20 @@ __global__ void k_scatter_grads(ScatterArgs a) {
         for (int g = 0; g < a.gd; ++g)
             if (a.dmem[g] >> k & 1ull) gd += rec[2 * a.ga + g];
         const double* t = a.det + (size_t(b) * a.Kd + k) * a.n_samples;
-        for (int q = 0; q < 4; ++q) {
-            const double w = a.w[e * 4 + q], dw = a.dwdt[e * 4 + q];
-            const int i = a.idx[e * 4 + q];
+        for (int q = 0; q < 2; ++q) {
+            const double w = wq[q], dw = dwq[q];
+            const int i = iq[q];
             if (a.g_det && w != 0.0) unsafeAtomicAdd(a.g_det + (size_t(b) * a.Kd + k) * a.n_samples + i, 2.0 * w * gd);
             if (dw != 0.0) dLdt += dw * 2.0 * gd * t[i];
         }
     }
     if (a.g_tsave) {
-        const int tn0 = a.tinfo[e * 4 + 0], tn1 = a.tinfo[e * 4 + 1], thi = a.tinfo[e * 4 + 2], tlo = a.tinfo[e * 4 + 3];
-        const double gtau = rec[a.NC] * a.tscale[e * 3 + 0];
-        if (tn0 >= 0) unsafeAtomicAdd(a.g_tsave + tn0, dLdt * a.tscale[e * 3 + 1]);
-        if (tn1 >= 0) unsafeAtomicAdd(a.g_tsave + tn1, dLdt * a.tscale[e * 3 + 2]);
-        if (thi >= 0) unsafeAtomicAdd(a.g_tsave + thi, gtau);
-        if (tlo >= 0) unsafeAtomicAdd(a.g_tsave + tlo, -gtau);
+        const StageBwdDev sb = a.sb[e];
+        const double gtau = rec[a.NC] * sb.tau_scale;
+        if (sb.tn0 >= 0) unsafeAtomicAdd(a.g_tsave + sb.tn0, dLdt * sb.tnw0);
+        if (sb.tn1 >= 0) unsafeAtomicAdd(a.g_tsave + sb.tn1, dLdt * sb.tnw1);
+        if (sb.t_hi >= 0) unsafeAtomicAdd(a.g_tsave + sb.t_hi, gtau);
+        if (sb.t_lo >= 0) unsafeAtomicAdd(a.g_tsave + sb.t_lo, -gtau);
     }
 }
 
@@ -769,6 +827,75 @@ __global__ void k_scatter_grads(ScatterArgs a) {
 #include "persist_kernels.hpp"
 #include "lane_kernels.hpp"
 static_assert(sizeof(PersistFactor) == 48, "plan.hpp sizes the factor table with 48 bytes per entry");
+
+// ------------------------------------------------------------------------------------------------
+// Host metadata -> device WITHOUT a copy engine or a synchronisation: the words travel as kernel arguments (the runtime
+// copies them into the launch packet before hipLaunchKernel returns, so the host buffer may die right away) and one
+// small workgroup writes them out.  Used for the per-exponential records (24 / 40 bytes each) and the pair tables.
+// ------------------------------------------------------------------------------------------------
+constexpr int kUploadWords = 448;  // 3584 bytes of payload per launch (kernel arguments are limited to 4 KiB)
+struct UploadChunk {
+    unsigned long long w[kUploadWords];
+};
+
+__global__ __launch_bounds__(256) void k_upload(unsigned long long* __restrict__ dst, UploadChunk c, int n) {
+    for (int i = threadIdx.x; i < n; i += 256) dst[i] = c.w[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Factor table of the one-launch sweeps (k_persist / k_lanes), built ON THE DEVICE from the per-exponential durations:
+// the scalars of factor f of a sub-exponential of duration tau are
+//   beta = -tau / (rho_d z_f),  gamma = 1 + tau sigma / (rho_d z_f),  both times exp(-i tau sigma) p(0) for the last factor
+// (factor_scalars on the host).  One thread per tsave interval walks its exponentials, sub-steps and factors.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxDegreeDev = 96;
+struct PTableArgs {
+    PersistFactor* out;
+    const double* tau_sub;      // [E]
+    const int32_t* nsub;        // [E]
+    const int32_t* step_begin;  // [T+1]
+    const int32_t* step_first;  // [T]: index of the interval's first factor
+    int T, degree;
+    double sigma, rho_design, p0r, p0i;
+    double roots[2 * kMaxDegreeDev];
+};
+
+__global__ __launch_bounds__(64) void k_build_ptable(PTableArgs a) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= a.T) return;
+    int idx = a.step_first[k];
+    const int first = idx;
+    const int e_end = a.step_begin[k + 1];
+    for (int e = a.step_begin[k]; e < e_end; ++e) {
+        const double tau = a.tau_sub[e];
+        const int ns = a.nsub[e];
+        double sn, cs;
+        sincos(-tau * a.sigma, &sn, &cs);
+        const double kr = cs * a.p0r - sn * a.p0i, ki = cs * a.p0i + sn * a.p0r;  // kappa = exp(-i tau sigma) p(0)
+        for (int sub = 0; sub < ns; ++sub)
+            for (int f = 0; f < a.degree; ++f, ++idx) {
+                // 1 / (rho_d z)
+                const double zr = a.rho_design * a.roots[2 * f], zi = a.rho_design * a.roots[2 * f + 1];
+                const double inv = 1.0 / (zr * zr + zi * zi);
+                const double ir = zr * inv, ii = -zi * inv;
+                double br = -tau * ir, bi = -tau * ii;
+                double gr = 1.0 + tau * a.sigma * ir, gi = tau * a.sigma * ii;
+                if (f == a.degree - 1) {
+                    const double nbr = br * kr - bi * ki, nbi = br * ki + bi * kr;
+                    const double ngr = gr * kr - gi * ki, ngi = gr * ki + gi * kr;
+                    br = nbr; bi = nbi; gr = ngr; gi = ngi;
+                }
+                const bool last = (e == e_end - 1) && (sub == ns - 1) && (f == a.degree - 1);
+                PersistFactor pf;
+                pf.gr = gr; pf.gi = gi; pf.br = br; pf.bi = bi;
+                pf.stage = e;
+                pf.save_index = last ? k + 1 : 0;
+                pf.step_first = first;
+                pf.pad = 0;
+                a.out[idx] = pf;
+            }
+    }
+}
 
 // ---- chained tile passes (chain_kernels.hpp) ------------------------------------------------------------------------
 // Tile layouts: every layout keeps a contiguous low run of >= 2^3 amplitudes so that global accesses stay coalesced.
@@ -781,16 +908,15 @@ struct LayoutDesc {
     uint32_t bits;  // amplitude-index bits covered by the tile
 };
 
-static int g_force_three_layouts = 0;  // kernel variant 7: three layouts wherever they are legal (A/B tests)
-
-int chain_layout_count(int N) {
-    if (N >= 23 || (g_force_three_layouts && N >= 21)) return 3;
+// force_three: kernel variant 7 — three layouts wherever they are legal (A/B tests)
+int chain_layout_count(int N, bool force_three) {
+    if (N >= 23 || (force_three && N >= 21)) return 3;
     return 2;
 }
 
-LayoutDesc chain_layout(int N, int which) {
+LayoutDesc chain_layout(int N, int which, bool force_three) {
     LayoutDesc d{};
-    const bool three = chain_layout_count(N) == 3;
+    const bool three = chain_layout_count(N, force_three) == 3;
     if (which == 0) {  // A
         d.lo = kTileBits;
         d.hs = kTileBits;
@@ -808,8 +934,6 @@ LayoutDesc chain_layout(int N, int which) {
     return d;
 }
 
-#include "chain2_kernels.hpp"
-
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -824,9 +948,47 @@ struct Runtime {
     int flags = 0;
     bool real_amp_grad = false;  // RydProblem.real_amp_grad: dL/dIm(amp) is not wanted
     bool prefer_direct = false;  // few tiles in flight: one-amplitude-per-thread kernels instead of the chained tile passes
+    // RydProblem.kernel_variant decoded (include/rydiff.h); nothing about the kernel choice lives outside this struct
+    int variant = 0;              // 0 auto | 1 direct | 2..4 chained tiles | 8 auto with LDS-tile kernels below 7 qubits
+    bool generic_direct = false;  // variant 9: direct kernels without the unrolled global-drive instantiations
+    bool force_three = false;     // variant 7: three tile layouts wherever they are legal
+    bool force_xcd = false;       // variant 10: trajectory-per-XCD placement of the chained tiles forced
+    int chain_lgt = 9;            // log2(threads per tile workgroup) of explicitly chosen chained variants
     GroupArgs garg{};
     PairArgs parg{};
 };
+
+// RydProblem.kernel_variant -> Runtime (include/rydiff.h lists the values)
+int decode_variant(const RydProblem* p, Runtime& rt) {
+    int v = p->kernel_variant;
+    if (v < 0 || v > 10 || v == 5 || v == 6) return fail(RYDIFF_EINVAL, "kernel_variant must be 0..4 or 7..10");
+    rt.generic_direct = v == 9;
+    if (v == 9) v = 1;
+    rt.force_three = v == 7;
+    if (v == 7) v = 0;
+    rt.force_xcd = v == 10;
+    if (v == 10) v = 0;
+    rt.variant = v;
+    rt.chain_lgt = v == 3 ? 8 : (v == 4 ? 10 : 9);
+    return RYDIFF_OK;
+}
+
+// metadata words -> device through kernel arguments (k_upload): asynchronous, the host buffer may die on return
+int upload_words(hipStream_t stream, void* dst, const void* src, size_t bytes) {
+    const size_t nwords = (bytes + 7) / 8;  // every destination region is 256-byte aligned and padded (plan.hpp: take)
+    const unsigned char* sp = static_cast<const unsigned char*>(src);
+    unsigned long long* dp = static_cast<unsigned long long*>(dst);
+    for (size_t w0 = 0; w0 < nwords; w0 += kUploadWords) {
+        const int n = int(std::min<size_t>(kUploadWords, nwords - w0));
+        UploadChunk c;
+        const size_t have = std::min<size_t>(size_t(n) * 8, bytes - w0 * 8);
+        memcpy(c.w, sp + w0 * 8, have);
+        if (have < size_t(n) * 8) memset(reinterpret_cast<unsigned char*>(c.w) + have, 0, size_t(n) * 8 - have);
+        hipLaunchKernelGGL(k_upload, dim3(1), dim3(256), 0, stream, dp + w0, c, n);
+        LAUNCH_CHECK();
+    }
+    return RYDIFF_OK;
+}
 
 std::mutex g_poly_mutex;
 std::vector<PolyDesign> g_poly_cache;
@@ -915,9 +1077,9 @@ int run_stats(const RydProblem* p, const Plan& pl, void* scratch, hipStream_t st
     dim3 grid((ns + 127) / 128, pl.Bc);
     hipLaunchKernelGGL(k_table_stats, grid, dim3(128), 0, stream, static_cast<unsigned long long*>(scratch), sa);
     LAUNCH_CHECK();
-    double host[5] = {0, 0, 0, 0, 0};
+    double host[6] = {0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(host, scratch, sizeof(host), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipStreamSynchronize(stream));  // the ONE synchronisation of the library: the bounds decide how many launches follow
     // interpolation weights: KRYLOV_SE uses convex combinations (sum |w| = 1); keep the general bound
     double wsum = 1.0;
     for (const auto& s : pl.stages) {
@@ -925,8 +1087,10 @@ int run_stats(const RydProblem* p, const Plan& pl, void* scratch, hipStream_t st
         for (int q = 0; q < 4; ++q) a += std::fabs(s.w[q]);
         wsum = std::max(wsum, a);
     }
+    // Gershgorin: the diagonal ranges over [-sum of negative U_ij, +sum of positive U_ij] (occupations are 0/1) plus the
+    // detuning range; the flip part has norm host[0] exactly (commuting single-qubit terms)
     hi = host[3] + wsum * (host[1] + host[0]);
-    lo = -wsum * (host[2] + host[0]);
+    lo = -host[5] - wsum * (host[2] + host[0]);
     flags = (host[4] != 0.0) ? 1 : 0;  // bit 0: some flip coefficient has a non-zero imaginary part (phase != 0)
     return RYDIFF_OK;
 }
@@ -949,8 +1113,9 @@ void fill_info(const Runtime& rt, double lo, double hi, size_t ws, RydPlanInfo* 
 // amplitudes in flight (N=13: 5.3 vs 9.4 us per pass, N=16 B=4: +13 %), and the same with gradients since the direct kernels
 // keep the full tape too and have unrolled instantiations for one global drive (N=18, 200 steps: 50 ms vs 69 ms chained; N=19:
 // 83 vs 78 ms).  Explicit kernel variants are left alone (A/B tests).
-bool few_tiles(const Plan& pl, bool with_gradients) {
-    if (g_kernel_variant != 0 || g_force_three_layouts) return false;
+bool few_tiles(const Runtime& rt, bool with_gradients) {
+    const Plan& pl = rt.pl;
+    if (rt.variant != 0 || rt.force_three || rt.force_xcd) return false;
     (void)with_gradients;  // with the unrolled global-drive direct kernels the crossover is 2^18 amplitudes either way
     return (size_t(pl.B) << pl.N) <= (size_t(1) << 18);
 }
@@ -960,10 +1125,14 @@ bool few_tiles(const Plan& pl, bool with_gradients) {
 // one state per tsave.
 bool full_tape_possible(const Plan& pl) { return pl.N > kPersistBwdMaxQubits && pl.n_pair == 0; }
 
-// common prologue of forward / backward: plan, (optional) stats, carve, upload metadata, expand coefficients, udiag
+// common prologue of forward / backward: plan, (optional) stats, carve, upload metadata, expand coefficients, udiag.
+// With `info` given nothing in here waits for the device.
 int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_t workspace_bytes, int need_tape,
             bool need_backward, hipStream_t stream, Runtime& rt) {
     std::string err;
+    if (!p) return fail(RYDIFF_EINVAL, "null problem");
+    int rc = decode_variant(p, rt);
+    if (rc) return rc;
     if (!build_plan(p, rt.pl, err)) return fail(err.find("not implemented") != std::string::npos ? RYDIFF_ENOTIMPL : RYDIFF_EINVAL, err);
     if (!workspace) return fail(RYDIFF_EINVAL, "null workspace");
     double lo, hi;
@@ -973,43 +1142,38 @@ int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_
         rt.flags = info->flags;
     } else {
         if (workspace_bytes < RYDIFF_PLAN_SCRATCH_BYTES) return fail(RYDIFF_EWORKSPACE, "workspace too small");
-        int rc = run_stats(p, rt.pl, workspace, stream, lo, hi, rt.flags);
+        rc = run_stats(p, rt.pl, workspace, stream, lo, hi, rt.flags);
         if (rc) return rc;
     }
     rt.real_amp_grad = p->real_amp_grad != 0;
     // the stage list of the continuous solver depends on the spectral width: rebuild it now that the width is known
     if (!build_plan(p, rt.pl, err, generator_half_width(rt.pl, lo, hi))) return fail(RYDIFF_EINVAL, err);
-    int rc = finish_runtime(rt, lo, hi);
+    rc = finish_runtime(rt, lo, hi);
     if (rc) return rc;
     Plan& pl = rt.pl;
     if (need_tape == 2 && !full_tape_possible(pl)) need_tape = 1;  // full tape only with chained passes
-    rt.prefer_direct = few_tiles(pl, need_backward || need_tape != 0);
+    rt.prefer_direct = few_tiles(rt, need_backward || need_tape != 0);
     const size_t need = carve(pl, need_tape, need_backward, std::max(rt.max_step_factors - 1, 1), rt.total_factors);
     if (workspace_bytes < need)
         return fail(RYDIFF_EWORKSPACE, "workspace too small: need " + std::to_string(need) + " bytes, got " + std::to_string(workspace_bytes));
     char* ws = static_cast<char*>(workspace);
     const size_t E = pl.stages.size();
-    // stage metadata -> device (pageable host memory: the runtime stages it before returning)
-    std::vector<int32_t> idx(E * 4);
-    std::vector<double> w(E * 4);
-    for (size_t e = 0; e < E; ++e)
-        for (int q = 0; q < 4; ++q) {
-            idx[e * 4 + q] = pl.stages[e].idx[q];
-            w[e * 4 + q] = pl.stages[e].w[q];
-        }
-    HIP_TRY(hipMemcpyAsync(ws + pl.off_meta_idx, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(ws + pl.off_meta_w, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    {   // per-exponential records -> device (as kernel arguments: no copy engine, no synchronisation)
+        std::vector<StageDev> sd(E);
+        for (size_t e = 0; e < E; ++e) sd[e] = {pl.stages[e].w[0], pl.stages[e].w[1], pl.stages[e].idx[0], pl.stages[e].idx[1]};
+        rc = upload_words(stream, ws + pl.off_meta_idx, sd.data(), E * sizeof(StageDev));
+        if (rc) return rc;
+    }
     if (pl.n_pair) {
-        HIP_TRY(hipMemcpyAsync(ws + pl.off_pair, pl.pair_tab.data(), pl.pair_tab.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+        rc = upload_words(stream, ws + pl.off_pair, pl.pair_tab.data(), pl.pair_tab.size() * sizeof(double));
+        if (rc) return rc;
         rt.parg.tab = reinterpret_cast<const double2*>(ws + pl.off_pair);
     }
-    HIP_TRY(hipStreamSynchronize(stream));  // idx/w are stack vectors: make sure the copies are done before they die
     if (pl.NC > 0) {
         ExpandArgs ea{};
         ea.amp = static_cast<const double2*>(p->amp_tables);
         ea.det = p->det_tables;
-        ea.idx = reinterpret_cast<const int32_t*>(ws + pl.off_meta_idx);
-        ea.w = reinterpret_cast<const double*>(ws + pl.off_meta_w);
+        ea.st = reinterpret_cast<const StageDev*>(ws + pl.off_meta_idx);
         ea.coef = reinterpret_cast<double*>(ws + pl.off_coef);
         ea.E = int(E);
         ea.n_samples = pl.n_samples;
@@ -1035,8 +1199,8 @@ int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_
         const unsigned tiles = unsigned(pl.dim >> kTileBits);
         double* split = reinterpret_cast<double*>(ws + pl.off_split);
         const size_t per_layout = kTileAmps + size_t(tiles) * 16;
-        for (int l = 0; l < chain_layout_count(pl.N); ++l) {
-            const LayoutDesc d = chain_layout(pl.N, l);
+        for (int l = 0; l < chain_layout_count(pl.N, rt.force_three); ++l) {
+            const LayoutDesc d = chain_layout(pl.N, l, rt.force_three);
             double* utt = split + l * per_layout;
             hipLaunchKernelGGL(k_build_split, dim3((kTileAmps + tiles + 255) / 256), dim3(256), 0, stream, utt, utt + kTileAmps,
                                p->u_pairs, pl.N, d.lo, d.hs, d.hb, tiles);
@@ -1083,12 +1247,10 @@ void build_step_chain(const Runtime& rt, int k, std::vector<ChainItem>& chain) {
     }
 }
 
-int launch_single_fwd(const Runtime& rt, char* ws, const double2* xin, double2* xout, int stage, const FactorScalars& s, hipStream_t stream);
-bool single_pass_enabled(const Runtime& rt);
-
 // one global drive on a 12..20-qubit register without pair terms: the unrolled direct kernels (k_factor_direct_global)
-bool direct_global_ok(const Plan& pl) {
-    return !g_generic_direct && pl.N >= 12 && pl.N <= 20 && pl.n_pair == 0 && pl.ga.n == 1 &&
+bool direct_global_ok(const Runtime& rt) {
+    const Plan& pl = rt.pl;
+    return !rt.generic_direct && pl.N >= 12 && pl.N <= 20 && pl.n_pair == 0 && pl.ga.n == 1 &&
            pl.ga.amp_index_mask[0] == (1u << pl.N) - 1u;
 }
 
@@ -1097,7 +1259,6 @@ int launch_factor(const Runtime& rt, char* ws, const double2* xin, double2* xout
                   const double* obs = nullptr, double* expect_slot = nullptr, bool* fused = nullptr) {
     const Plan& pl = rt.pl;
     if (fused) *fused = false;
-    if (single_pass_enabled(rt)) return launch_single_fwd(rt, ws, xin, xout, stage, s, stream);
     FactorArgs fa{};
     fa.xin = xin;
     fa.xout = xout;
@@ -1112,7 +1273,7 @@ int launch_factor(const Runtime& rt, char* ws, const double2* xin, double2* xout
     fa.g = rt.garg;
     fa.pair = rt.parg;
     dim3 grid(unsigned((pl.dim + 255) / 256), pl.B);
-    if (direct_global_ok(pl)) {
+    if (direct_global_ok(rt)) {
         if (obs && expect_slot) {
             fa.obs = obs;
             fa.expect_slot = expect_slot;
@@ -1147,19 +1308,19 @@ struct KernelStep {
     int sta;
 };
 
-void chain_schedule(int N, int F, std::vector<KernelStep>& ks) {
+void chain_schedule(int N, bool force_three, int F, std::vector<KernelStep>& ks) {
     ks.clear();
-    if (chain_layout_count(N) == 2) {
+    if (chain_layout_count(N, force_three) == 2) {
         for (int k = 0; k <= F; ++k)
-            ks.push_back({k & 1, k > 0 ? chain_layout(N, (k - 1) & 1).bits : 0u, k - 1, true, k < F ? k : -1});
+            ks.push_back({k & 1, k > 0 ? chain_layout(N, (k - 1) & 1, force_three).bits : 0u, k - 1, true, k < F ? k : -1});
         return;
     }
-    const uint32_t bbits = chain_layout(N, 1).bits;
+    const uint32_t bbits = chain_layout(N, 1, force_three).bits;
     auto end_layout = [](int m) { return (m & 1) ? 2 : 0; };  // factor m starts in A (even m) or C (odd m)
     for (int m = 0; m <= F; ++m) {
-        const uint32_t cov = m > 0 ? (chain_layout(N, end_layout(m - 1)).bits | bbits) : 0u;
+        const uint32_t cov = m > 0 ? (chain_layout(N, end_layout(m - 1), force_three).bits | bbits) : 0u;
         ks.push_back({end_layout(m), cov, m - 1, true, m < F ? m : -1});
-        if (m < F) ks.push_back({1, chain_layout(N, end_layout(m)).bits, m, false, -1});
+        if (m < F) ks.push_back({1, chain_layout(N, end_layout(m), force_three).bits, m, false, -1});
     }
 }
 
@@ -1174,7 +1335,7 @@ uint32_t to_tile_mask(const LayoutDesc& d, uint32_t index_mask) {
 
 bool chain_enabled(const Runtime& rt) {
     const int N = rt.pl.N;
-    if (g_kernel_variant == 1 || g_kernel_variant == 5 || rt.pl.n_pair) return false;  // pair terms: direct kernels
+    if (rt.variant == 1 || rt.pl.n_pair) return false;  // pair terms: direct kernels
     return N > kTileBits && N <= 28 && !rt.prefer_direct;
 }
 
@@ -1195,7 +1356,8 @@ struct ChainStep {
     const double2* x_sta = nullptr;
     double cb_fin_r = 0, cb_fin_i = 0, cb_sta_r = 0, cb_sta_i = 0;
     double* wtot = nullptr;
-    bool single = false;  // single-pass mode: complete factor in one launch (partner tiles from L2 / Infinity Cache)
+    // fused cotangent injection (adjoint): save point the vector completed by this launch belongs to, -1: none
+    int inject_k = -1;
     // fused expectation (forward)
     const double* obs = nullptr;
     double* expect_slot = nullptr;
@@ -1204,43 +1366,54 @@ struct ChainStep {
 };
 
 template <int LGT, bool CPLX, bool BWD, bool FAST = false>
-int launch_chain_t(const ChainArgs& ca, unsigned tiles, int B, hipStream_t stream) {
-    if constexpr (!FAST) {  // one global drive, at most one detuning group, no partner-tile loads: the loop-free instantiation
-        if (ca.ga == 1 && ca.gd <= 1 && ca.sta_mask[0] == (1u << kTileBits) - 1u && ca.hi_mask[0] == 0)
-            return launch_chain_t<LGT, CPLX, BWD, true>(ca, tiles, B, stream);
+int launch_chain_t(const ChainArgs& ca, unsigned tiles, hipStream_t stream) {
+    if constexpr (!FAST) {  // one global drive, at most one detuning group: the loop-free instantiation
+        if (ca.ga == 1 && ca.gd <= 1 && ca.sta_mask[0] == (1u << kTileBits) - 1u)
+            return launch_chain_t<LGT, CPLX, BWD, true>(ca, tiles, stream);
     }
-    static bool attr_set = false;
     // tile + reduction scratch: one double per wave (forward), [4 ga + gd] slots per wave (adjoint: parked gradient partials)
     const size_t nw = (size_t(1) << LGT) / 64;
     const size_t max_lds = (size_t(1) << kTileBits) * sizeof(double2) + 256 + (BWD ? size_t(5) * kMaxGroups * nw * sizeof(double) : 0);
     const size_t lds = (size_t(1) << kTileBits) * sizeof(double2) + 256 + (BWD ? size_t(4 * ca.ga + ca.gd) * nw * sizeof(double) : 0);
     auto kern = k_chain<kTileBits, LGT, CPLX, BWD, FAST>;
-    if (!attr_set) {
+    // once per instantiation and process; idempotent, so a race between two first callers is harmless
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set.load(std::memory_order_acquire)) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(max_lds)));
-        attr_set = true;
+        attr_set.store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL(kern, dim3(tiles, B), dim3(1 << LGT), lds, stream, ca);
+    const dim3 grid = ca.xcd_place ? dim3(tiles * 8u, unsigned(ca.b_count + 7) / 8u) : dim3(tiles, unsigned(ca.b_count));
+    hipLaunchKernelGGL(kern, grid, dim3(1 << LGT), lds, stream, ca);
     LAUNCH_CHECK();
     return RYDIFF_OK;
 }
 
 template <int LGT>
-int launch_chain_l(const ChainArgs& ca, unsigned tiles, int B, bool cplx, bool bwd, hipStream_t stream) {
+int launch_chain_l(const ChainArgs& ca, unsigned tiles, bool cplx, bool bwd, hipStream_t stream) {
     // the adjoint needs both partner sums (plain and signed) unless the coefficients are real AND the caller only uses the
     // real part of the amplitude gradients (RydProblem.real_amp_grad): then `cplx` arrives false here
-    if (bwd) return cplx ? launch_chain_t<LGT, true, true>(ca, tiles, B, stream) : launch_chain_t<LGT, false, true>(ca, tiles, B, stream);
-    return cplx ? launch_chain_t<LGT, true, false>(ca, tiles, B, stream) : launch_chain_t<LGT, false, false>(ca, tiles, B, stream);
+    if (bwd) return cplx ? launch_chain_t<LGT, true, true>(ca, tiles, stream) : launch_chain_t<LGT, false, true>(ca, tiles, stream);
+    return cplx ? launch_chain_t<LGT, true, false>(ca, tiles, stream) : launch_chain_t<LGT, false, false>(ca, tiles, stream);
 }
 
-int g_chain_lgt = 9;  // log2(threads per tile workgroup): 512 threads, 8 amplitudes per thread
+// cotangents handed to the backward call (fused injection, see ChainArgs / FactorBwdArgs)
+struct InjectSource {
+    const double2* gstate = nullptr;  // grad_states [n_tsave][B][dim] or nullptr
+    const double* gexp = nullptr;     // grad_expect [n_obs][n_tsave][B] or nullptr
+    const double* obs = nullptr;      // [n_obs][dim]
+    int n_obs = 0;
+    bool any() const { return gstate || gexp; }
+};
 
-int launch_chain2(const Runtime& rt, char* ws, const ChainStep& cs, hipStream_t stream);
-bool chain2_enabled(const Runtime& rt);
+// the trajectories a chain covers and how its launches are placed (Runtime::xcd_group)
+struct BatchSlice {
+    int first = 0, count = 0;
+    bool xcd = false;  // trajectory-per-XCD placement + L2-resident in-place vectors
+};
 
-int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, hipStream_t stream) {
+int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, const BatchSlice& bs, const InjectSource& inj, hipStream_t stream) {
     const Plan& pl = rt.pl;
-    if (!cs.single && chain2_enabled(rt)) return launch_chain2(rt, ws, cs, stream);
-    const LayoutDesc X = chain_layout(pl.N, cs.layout);
+    const LayoutDesc X = chain_layout(pl.N, cs.layout, rt.force_three);
     ChainArgs ca{};
     ca.u = cs.u;
     ca.p = cs.p;
@@ -1271,13 +1444,15 @@ int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, hipStream_t s
     ca.write_v = cs.write_v;
     ca.ga = pl.ga.n;
     ca.gd = pl.gd.n;
+    ca.xcd_place = bs.xcd ? 1 : 0;
+    ca.resident = bs.xcd ? 1 : 0;
+    ca.b_first = bs.first;
+    ca.b_count = bs.count;
     const uint32_t prev_bits = cs.covered_bits;
     for (int g = 0; g < pl.ga.n; ++g) {
         ca.fin_mask[g] = to_tile_mask(X, pl.ga.amp_index_mask[g] & ~prev_bits);
         ca.sta_mask[g] = to_tile_mask(X, pl.ga.amp_index_mask[g]);
-        ca.hi_mask[g] = cs.single ? (pl.ga.amp_index_mask[g] & ~X.bits) : 0u;
     }
-    ca.xcd_swizzle = (cs.single && (pl.dim >> kTileBits) >= 64 && ((pl.dim >> kTileBits) % 8) == 0) ? 1 : 0;
     for (int g = 0; g < pl.gd.n; ++g) {
         ca.dmask[g] = pl.gd.amp_index_mask[g];
         ca.dcnt[g] = pl.gd.count[g];
@@ -1300,120 +1475,25 @@ int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, hipStream_t s
         ca.cb_sta_r = cs.cb_sta_r;
         ca.cb_sta_i = cs.cb_sta_i;
         ca.wtot = cs.wtot;
+        if (cs.inject_k >= 0 && cs.has_p && inj.any()) {
+            const size_t sv = size_t(pl.B) * pl.dim;
+            ca.inj_gstate = inj.gstate ? inj.gstate + size_t(cs.inject_k) * sv : nullptr;
+            ca.inj_gexp = inj.gexp ? inj.gexp + size_t(cs.inject_k) * pl.B : nullptr;
+            ca.inj_obs = inj.obs;
+            ca.inj_n_obs = inj.n_obs;
+            ca.inj_ostride = long(pl.T + 1) * pl.B;
+        }
     }
     const unsigned tiles = unsigned(pl.dim >> kTileBits);
     const bool cplx = (rt.flags & 1) != 0 || (cs.bwd && !rt.real_amp_grad);
     // auto: 1024 threads per tile for the forward passes, 512 for the (register-hungrier) adjoint passes
     // (the real-drive adjoint, without the signed sums, fits 1024 threads too: measured 2710 -> 2767 steps/s on C3)
-    const int lgt = g_kernel_variant == 0 ? ((cs.bwd && cplx) ? 9 : 10) : g_chain_lgt;
+    const int lgt = rt.variant == 0 ? ((cs.bwd && cplx) ? 9 : 10) : rt.chain_lgt;
     switch (lgt) {
-        case 8: return launch_chain_l<8>(ca, tiles, pl.B, cplx, cs.bwd, stream);
-        case 10: return launch_chain_l<10>(ca, tiles, pl.B, cplx, cs.bwd, stream);
-        default: return launch_chain_l<9>(ca, tiles, pl.B, cplx, cs.bwd, stream);
+        case 8: return launch_chain_l<8>(ca, tiles, cplx, cs.bwd, stream);
+        case 10: return launch_chain_l<10>(ca, tiles, cplx, cs.bwd, stream);
+        default: return launch_chain_l<9>(ca, tiles, cplx, cs.bwd, stream);
     }
-}
-
-// ---- sub-tile pipelined variant (chain2_kernels.hpp): 13 <= N <= 22 -------------------------------------------------
-bool chain2_enabled(const Runtime& rt) {
-    const int N = rt.pl.N;
-    // measured on C3: 16.0 us per pass vs 15.1 us for k_chain<12,10> (the extra barriers and LDS-bit reads eat the
-    // overlap it recovers), so it is opt-in (variant 6) until it wins
-    if (g_kernel_variant != 6) return false;
-    return N > kTileBits && N <= 22;
-}
-
-template <int LGT, bool CPLX, bool BWD>
-int launch_chain2_t(const Chain2Args& ca, unsigned tiles, int B, hipStream_t stream) {
-    static bool attr_set = false;
-    const size_t lds = (size_t(2) << 11) * sizeof(double2) + 256;
-    auto kern = k_chain2<LGT, CPLX, BWD>;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(tiles, B), dim3(1 << LGT), lds, stream, ca);
-    LAUNCH_CHECK();
-    return RYDIFF_OK;
-}
-
-int launch_chain2(const Runtime& rt, char* ws, const ChainStep& cs, hipStream_t stream) {
-    const Plan& pl = rt.pl;
-    const LayoutDesc X = chain_layout(pl.N, cs.layout);
-    const int lo_b = 2 * kTileBits - pl.N;
-    auto excluded = [&](int layout) { return layout == 0 ? lo_b - 1 : lo_b - 2; };  // index bit excluded from the local flips
-    Chain2Args ca{};
-    ca.u = cs.u;
-    ca.p = cs.p;
-    ca.v_out = cs.v_out;
-    ca.q_out = cs.q_out;
-    {
-        const size_t per_layout = kTileAmps + size_t(pl.dim >> kTileBits) * 16;
-        const double* split = reinterpret_cast<const double*>(ws + pl.off_split) + size_t(cs.layout) * per_layout;
-        ca.utt = split;
-        ca.vr = split + kTileAmps;
-    }
-    const double* coef = reinterpret_cast<const double*>(ws + pl.off_coef);
-    ca.coef_fin = coef + size_t(std::max(cs.fin_stage, 0)) * pl.NC;
-    ca.coef_sta = coef + size_t(std::max(cs.sta_stage, 0)) * pl.NC;
-    ca.coef_bstride = pl.Bc > 1 ? long(pl.stages.size()) * pl.NC : 0;
-    ca.fb_r = cs.fin.br;
-    ca.fb_i = cs.fin.bi;
-    ca.sg_r = cs.sta.gr;
-    ca.sg_i = cs.sta.gi;
-    ca.sb_r = cs.sta.br;
-    ca.sb_i = cs.sta.bi;
-    ca.lo = X.lo;
-    ca.hs = X.hs;
-    ca.hb = X.hb;
-    ca.sub_bit = excluded(cs.layout);  // both layouts keep their low index bits at the same super-tile positions
-    ca.dim = uint32_t(pl.dim);
-    ca.has_p = cs.has_p;
-    ca.has_q = cs.has_q;
-    ca.write_v = cs.write_v;
-    ca.ga = pl.ga.n;
-    ca.gd = pl.gd.n;
-    uint32_t prev_cov = 0;
-    if (cs.prev_layout >= 0) prev_cov = chain_layout(pl.N, cs.prev_layout).bits & ~(1u << excluded(cs.prev_layout));
-    for (int g = 0; g < pl.ga.n; ++g) {
-        uint32_t fm = 0, sm = 0;
-        for (int c = 0; c < 11; ++c) {
-            const int tb = c < ca.sub_bit ? c : c + 1;
-            const int gb = tb < X.lo ? tb : X.hs + (tb - X.lo);
-            if (pl.ga.amp_index_mask[g] >> gb & 1u) {
-                sm |= 1u << c;
-                if (!(prev_cov >> gb & 1u)) fm |= 1u << c;
-            }
-        }
-        ca.fin_mask[g] = fm;
-        ca.sta_mask[g] = sm;
-    }
-    for (int g = 0; g < pl.gd.n; ++g) {
-        ca.dmask[g] = pl.gd.amp_index_mask[g];
-        ca.dcnt[g] = pl.gd.count[g];
-    }
-    ca.obs = cs.obs;
-    ca.expect_slot = cs.expect_slot;
-    ca.n_obs = cs.n_obs;
-    ca.exp_ostride = cs.exp_ostride;
-    if (cs.bwd) {
-        double* ge = reinterpret_cast<double*>(ws + pl.off_ge);
-        const long ge_rec = long(kGradReplicas) * (pl.NC + 1);
-        ca.x_fin = cs.x_fin;
-        ca.x_sta = cs.x_sta;
-        ca.ge_fin = ge + size_t(std::max(cs.fin_stage, 0)) * ge_rec;
-        ca.ge_sta = ge + size_t(std::max(cs.sta_stage, 0)) * ge_rec;
-        ca.ge_bstride = pl.Bc > 1 ? long(pl.stages.size()) * ge_rec : 0;
-        ca.ge_rstride = pl.NC + 1;
-        ca.cb_fin_r = cs.cb_fin_r;
-        ca.cb_fin_i = cs.cb_fin_i;
-        ca.cb_sta_r = cs.cb_sta_r;
-        ca.cb_sta_i = cs.cb_sta_i;
-        ca.wtot = cs.wtot;
-    }
-    const unsigned tiles = unsigned(pl.dim >> kTileBits);
-    const bool cplx = (rt.flags & 1) != 0;
-    if (cs.bwd) return launch_chain2_t<9, true, true>(ca, tiles, pl.B, stream);
-    return cplx ? launch_chain2_t<10, true, false>(ca, tiles, pl.B, stream) : launch_chain2_t<10, false, false>(ca, tiles, pl.B, stream);
 }
 
 // Run `items` (factors, in order) as a chain starting from the complete vector `start`.
@@ -1422,14 +1502,18 @@ int launch_chain2(const Runtime& rt, char* ws, const ChainStep& cs, hipStream_t 
 // skip_last_finish: do not finish the last factor (its output is not needed) — used by the backward recompute.
 template <class DstFn, class DoneFn, class ExpFn>
 int run_chain(const Runtime& rt, char* ws, const std::vector<ChainItem>& items, const double2* start, DstFn dst, DoneFn on_done,
-              ExpFn exp_slot, bool skip_last_finish, hipStream_t stream) {
+              ExpFn exp_slot, bool skip_last_finish, const BatchSlice& bs, hipStream_t stream) {
     const Plan& pl = rt.pl;
     double2* pp[2] = {reinterpret_cast<double2*>(ws + pl.off_pp0), reinterpret_cast<double2*>(ws + pl.off_pp1)};
     const int F = int(items.size()) - (skip_last_finish ? 1 : 0);  // the last factor is not even started then
     if (F <= 0) return RYDIFF_OK;
     std::vector<KernelStep> ks;
-    chain_schedule(pl.N, F, ks);
+    chain_schedule(pl.N, rt.force_three, F, ks);
     const double2* cur = start;
+    const InjectSource no_inj{};
+    // L2-resident placement: partials are rewritten IN PLACE (a workgroup reads and writes only its own tile elements), so
+    // the live set of a trajectory is one complete vector + one partial
+    auto ppsel = [&](size_t k) { return bs.xcd ? pp[0] : pp[k & 1]; };
     for (size_t k = 0; k < ks.size(); ++k) {
         const KernelStep& st = ks[k];
         ChainStep cs{};
@@ -1439,11 +1523,11 @@ int run_chain(const Runtime& rt, char* ws, const std::vector<ChainItem>& items, 
         cs.u = cur;
         cs.has_p = st.fin >= 0;
         cs.has_q = st.sta >= 0;
-        cs.p = cs.has_p ? pp[(k - 1) & 1] : nullptr;
-        cs.q_out = cs.has_q ? pp[k & 1] : nullptr;
+        cs.p = cs.has_p ? ppsel(k - 1) : nullptr;
+        cs.q_out = cs.has_q ? ppsel(k) : nullptr;
         cs.write_v = cs.has_p;
         if (cs.has_p) {
-            cs.v_out = st.completes ? dst(st.fin) : pp[k & 1];  // a middle pass hands the extended partial on
+            cs.v_out = st.completes ? dst(st.fin) : ppsel(k);  // a middle pass hands the extended partial on
             cs.fin_stage = items[st.fin].stage;
             cs.fin = items[st.fin].s;
             if (!cs.v_out) return fail(RYDIFF_EINVAL, "internal: chain destination missing");
@@ -1453,7 +1537,7 @@ int run_chain(const Runtime& rt, char* ws, const std::vector<ChainItem>& items, 
         }
         cs.sta_stage = cs.has_q ? items[st.sta].stage : -1;
         if (cs.has_q) cs.sta = items[st.sta].s;
-        int rc = launch_chain(rt, ws, cs, stream);
+        int rc = launch_chain(rt, ws, cs, bs, no_inj, stream);
         if (rc) return rc;
         if (cs.has_p && st.completes) {
             cur = cs.v_out;
@@ -1464,48 +1548,22 @@ int run_chain(const Runtime& rt, char* ws, const std::vector<ChainItem>& items, 
     return RYDIFF_OK;
 }
 
-bool single_pass_enabled(const Runtime& rt) {
-    const int N = rt.pl.N;
-    if (g_kernel_variant == 5) return N > kTileBits && N <= 24 && rt.pl.n_pair == 0;
-    return false;
-}
-
-// one launch per factor: q_out = (gamma + beta H) u, complete (single-pass mode of k_chain)
-int launch_single(const Runtime& rt, char* ws, const double2* xin, double2* xout, const ChainItem& it, hipStream_t stream,
-                  const double* obs = nullptr, double* expect_slot = nullptr) {
-    (void)obs; (void)expect_slot;
-    ChainStep cs{};
-    cs.single = true;
-    cs.layout = 0;
-    cs.prev_layout = -1;
-    cs.u = xin;
-    cs.has_p = 0;
-    cs.has_q = 1;
-    cs.write_v = 0;
-    cs.q_out = xout;
-    cs.fin_stage = -1;
-    cs.sta_stage = it.stage;
-    cs.sta = it.s;
-    return launch_chain(rt, ws, cs, stream);
-}
-
-int launch_single_fwd(const Runtime& rt, char* ws, const double2* xin, double2* xout, int stage, const FactorScalars& s, hipStream_t stream) {
-    ChainItem it{stage, s};
-    return launch_single(rt, ws, xin, xout, it, stream);
-}
-
-// Adjoint sweep of one tsave interval as a chain.  `items` are the interval's forward factors (in forward order),
-// xs[i] the input of factor i, `lam_in` the cotangent w.r.t. the interval's output; the cotangent w.r.t. its input ends
-// up in `lam_out`.  on_stage_end(stage, lam, x_out) is called with the complete cotangent at every exponential's output.
+// Adjoint sweep of consecutive tsave intervals as ONE chain.  `items` are the forward factors (in forward order), xs[i] the
+// input of factor i, `lam_in` the cotangent w.r.t. the output of the last one; the cotangent w.r.t. the first one's input ends
+// up in lam_bufs[cl].  save_k[i] >= 0: the input of factor i is the state at save point save_k[i] — the launch that completes
+// the cotangent there also adds the cotangent injected at that save point (fused).  on_stage_end(stage, lam, x_out) is called
+// with the complete cotangent at every exponential's output.
 template <class StageEndFn>
 int run_chain_bwd(const Runtime& rt, char* ws, const std::vector<ChainItem>& items, const std::vector<const double2*>& xs,
-                  const double2* lam_in, double2* lam_bufs[2], int& cl, double* wtot, StageEndFn on_stage_end, hipStream_t stream) {
+                  const std::vector<int>& save_k, const double2* lam_in, double2* lam_bufs[2], int& cl, double* wtot,
+                  StageEndFn on_stage_end, const BatchSlice& bs, const InjectSource& inj, hipStream_t stream) {
     const Plan& pl = rt.pl;
     double2* pp[2] = {reinterpret_cast<double2*>(ws + pl.off_pp0), reinterpret_cast<double2*>(ws + pl.off_pp1)};
     const int M = int(items.size());
     std::vector<KernelStep> ks;
-    chain_schedule(pl.N, M, ks);
+    chain_schedule(pl.N, rt.force_three, M, ks);
     const double2* cur = lam_in;
+    auto ppsel = [&](size_t k) { return bs.xcd ? pp[0] : pp[k & 1]; };
     // adjoint factor index a = 0..M-1 corresponds to forward factor f = M-1-a
     for (size_t k = 0; k < ks.size(); ++k) {
         const KernelStep& st = ks[k];
@@ -1517,8 +1575,8 @@ int run_chain_bwd(const Runtime& rt, char* ws, const std::vector<ChainItem>& ite
         cs.u = cur;
         cs.has_p = st.fin >= 0;
         cs.has_q = st.sta >= 0;
-        cs.p = cs.has_p ? pp[(k - 1) & 1] : nullptr;
-        cs.q_out = cs.has_q ? pp[k & 1] : nullptr;
+        cs.p = cs.has_p ? ppsel(k - 1) : nullptr;
+        cs.q_out = cs.has_q ? ppsel(k) : nullptr;
         cs.write_v = cs.has_p;
         cs.wtot = wtot;
         if (cs.has_p) {
@@ -1530,11 +1588,12 @@ int run_chain_bwd(const Runtime& rt, char* ws, const std::vector<ChainItem>& ite
             cs.cb_fin_i = it.s.bi;
             cs.x_fin = xs[f];
             if (st.completes) {
-                cl ^= 1;
+                if (!bs.xcd) cl ^= 1;  // L2-resident placement rewrites the cotangent in place
                 cs.v_out = lam_bufs[cl];
-                if (cs.v_out == cur) return fail(RYDIFF_EINVAL, "internal: cotangent ping-pong clash");
+                if (!bs.xcd && cs.v_out == cur) return fail(RYDIFF_EINVAL, "internal: cotangent ping-pong clash");
+                cs.inject_k = save_k[f];
             } else {
-                cs.v_out = pp[k & 1];
+                cs.v_out = ppsel(k);
             }
         }
         if (cs.has_q) {
@@ -1545,13 +1604,13 @@ int run_chain_bwd(const Runtime& rt, char* ws, const std::vector<ChainItem>& ite
             cs.cb_sta_r = it.s.br;
             cs.cb_sta_i = it.s.bi;
             cs.x_sta = xs[f];
-            // the cotangent `cur` at the output of the interval's last factor: exponential boundary for dL/dtau
+            // the cotangent `cur` at the output of the chain's last factor: exponential boundary for dL/dtau
             if (st.sta == 0) {
                 int rc = on_stage_end(it.stage, cur, xs[M]);
                 if (rc) return rc;
             }
         }
-        int rc = launch_chain(rt, ws, cs, stream);
+        int rc = launch_chain(rt, ws, cs, bs, inj, stream);
         if (rc) return rc;
         if (cs.has_p && st.completes) {
             cur = cs.v_out;  // complete cotangent at the INPUT of forward factor f = output of forward factor f-1
@@ -1566,7 +1625,7 @@ int run_chain_bwd(const Runtime& rt, char* ws, const std::vector<ChainItem>& ite
 }
 
 // ---- persistent small-N forward (k_persist) ------------------------------------------------------------------------
-bool persist_enabled(const Runtime& rt) { return g_kernel_variant != 1 && rt.pl.N <= kTileBits; }
+bool persist_enabled(const Runtime& rt) { return rt.variant != 1 && rt.pl.N <= kTileBits; }
 
 template <int LT, bool CPLX>
 int launch_persist_t(const PersistArgs& pa, int B, hipStream_t stream) {
@@ -1597,13 +1656,13 @@ int launch_lanes_fwd_t(const PersistArgs& pa, int B, hipStream_t stream) {
 }
 
 // one amplitude per lane of one wave (lane_kernels.hpp); variant 8 keeps the LDS-tile kernels for A/B tests
-bool lanes_enabled(int N, int ga, int gd, int n_pair) {
-    return g_kernel_variant != 8 && N <= kLaneMaxQubits && n_pair <= kLanePairMax && ga <= kPersistGroups && gd <= kPersistGroups;
+bool lanes_enabled(int variant, int N, int ga, int gd, int n_pair) {
+    return variant != 8 && N <= kLaneMaxQubits && n_pair <= kLanePairMax && ga <= kPersistGroups && gd <= kPersistGroups;
 }
 
 template <bool CPLX>
-int launch_persist(int N, const PersistArgs& pa, int B, hipStream_t stream) {
-    if (lanes_enabled(N, pa.ga, pa.gd, pa.pair.n) && pa.n_factors > 0) {
+int launch_persist(int variant, int N, const PersistArgs& pa, int B, hipStream_t stream) {
+    if (lanes_enabled(variant, N, pa.ga, pa.gd, pa.pair.n) && pa.n_factors > 0) {
         switch (N) {
             case 1: return launch_lanes_fwd_t<1, CPLX>(pa, B, stream);
             case 2: return launch_lanes_fwd_t<2, CPLX>(pa, B, stream);
@@ -1655,8 +1714,8 @@ int launch_lanes_bwd_t(const PersistBwdArgs& pa, int B, hipStream_t stream) {
 }
 
 template <bool CPLX>
-int launch_persist_bwd(int N, const PersistBwdArgs& pa, int B, hipStream_t stream) {
-    if (lanes_enabled(N, pa.ga, pa.gd, pa.pair.n) && pa.n_factors > 0) {
+int launch_persist_bwd(int variant, int N, const PersistBwdArgs& pa, int B, hipStream_t stream) {
+    if (lanes_enabled(variant, N, pa.ga, pa.gd, pa.pair.n) && pa.n_factors > 0) {
         switch (N) {
             case 1: return launch_lanes_bwd_t<1, CPLX>(pa, B, stream);
             case 2: return launch_lanes_bwd_t<2, CPLX>(pa, B, stream);
@@ -1681,21 +1740,79 @@ int launch_persist_bwd(int N, const PersistBwdArgs& pa, int B, hipStream_t strea
     }
 }
 
-// every factor of the run, in order, with the save point its output belongs to (0 = none)
-void build_persist_table(const Runtime& rt, std::vector<PersistFactor>& table) {
-    std::vector<ChainItem> chain;
-    table.clear();
-    for (int k = 0; k < rt.pl.T; ++k) {
-        build_step_chain(rt, k, chain);
-        const int first = int(table.size());
-        for (size_t i = 0; i < chain.size(); ++i)
-            table.push_back({chain[i].s.gr, chain[i].s.gi, chain[i].s.br, chain[i].s.bi, chain[i].stage,
-                             i + 1 == chain.size() ? k + 1 : 0, first, 0});
+// Factor table of the one-launch sweeps: every factor of the run, in order, with the save point its output belongs to (0 = none).
+// Built ON THE DEVICE (k_build_ptable) from four small per-interval / per-exponential arrays that travel as kernel arguments.
+int build_persist_table_device(const Runtime& rt, char* ws, hipStream_t stream, int* n_factors) {
+    const Plan& pl = rt.pl;
+    const size_t E = pl.stages.size();
+    if (rt.poly.degree > kMaxDegreeDev) return fail(RYDIFF_ENOTIMPL, "polynomial degree beyond the on-device factor table builder");
+    if (size_t(rt.total_factors) * sizeof(PersistFactor) > pl.ptable_bytes) return fail(RYDIFF_EWORKSPACE, "internal: factor table does not fit");
+    std::vector<int32_t> begin(pl.step_begin.begin(), pl.step_begin.end()), first(pl.T + 1, 0), nsub(E);
+    std::vector<double> tau(E);
+    for (size_t e = 0; e < E; ++e) {
+        nsub[e] = pl.stages[e].nsub;
+        tau[e] = pl.stages[e].tau / pl.stages[e].nsub;
     }
+    for (int k = 0; k < pl.T; ++k) {
+        int64_t f = 0;
+        for (int e = pl.step_begin[k]; e < pl.step_begin[k + 1]; ++e) f += int64_t(pl.stages[e].nsub) * rt.poly.degree;
+        first[k + 1] = int32_t(first[k] + f);
+    }
+    int rc = upload_words(stream, ws + pl.off_pm_begin, begin.data(), begin.size() * sizeof(int32_t));
+    if (!rc) rc = upload_words(stream, ws + pl.off_pm_first, first.data(), first.size() * sizeof(int32_t));
+    if (!rc) rc = upload_words(stream, ws + pl.off_pm_tau, tau.data(), tau.size() * sizeof(double));
+    if (!rc) rc = upload_words(stream, ws + pl.off_pm_nsub, nsub.data(), nsub.size() * sizeof(int32_t));
+    if (rc) return rc;
+    PTableArgs ta{};
+    ta.out = reinterpret_cast<PersistFactor*>(ws + pl.off_ptable);
+    ta.tau_sub = reinterpret_cast<const double*>(ws + pl.off_pm_tau);
+    ta.nsub = reinterpret_cast<const int32_t*>(ws + pl.off_pm_nsub);
+    ta.step_begin = reinterpret_cast<const int32_t*>(ws + pl.off_pm_begin);
+    ta.step_first = reinterpret_cast<const int32_t*>(ws + pl.off_pm_first);
+    ta.T = pl.T;
+    ta.degree = rt.poly.degree;
+    ta.sigma = rt.sigma;
+    ta.rho_design = rt.rho_design;
+    ta.p0r = rt.poly.p0.real();
+    ta.p0i = rt.poly.p0.imag();
+    for (int f = 0; f < rt.poly.degree; ++f) {
+        ta.roots[2 * f] = rt.poly.roots[f].real();
+        ta.roots[2 * f + 1] = rt.poly.roots[f].imag();
+    }
+    hipLaunchKernelGGL(k_build_ptable, dim3(unsigned(pl.T + 63) / 64), dim3(64), 0, stream, ta);
+    LAUNCH_CHECK();
+    *n_factors = int(rt.total_factors);
+    return RYDIFF_OK;
 }
 
 }  // namespace
 
+
+
+namespace {
+
+// Trajectory-per-XCD placement of the chained tile passes ("Batches of L2-sized trajectories"): a launch
+// covers a GROUP of 8 m trajectories, trajectory -> XCD by workgroup id % 8, vectors rewritten in place with plain loads and
+// stores, so that the complete vector + partial of m trajectories (m * 32 * 2^N bytes) stay in each XCD's 4 MiB L2 from pass to
+// pass and only the write-back crosses the fabric.  Every group runs its WHOLE sweep before the next one starts.  Returns the
+// group size (0: off).  Placement changes speed only: results are the same as with the plain grid (A/B-tested).
+int xcd_group_size(const Runtime& rt) {
+    const Plan& pl = rt.pl;
+    if (!chain_enabled(rt) || chain_layout_count(pl.N, rt.force_three) != 2) return 0;
+    const size_t live = size_t(32) << pl.N;    // complete vector + partial of one trajectory
+    const size_t budget = size_t(3) << 20;     // of the 4 MiB L2 (the rest: tape lines on their way out, tables)
+    if (!rt.force_xcd) {
+#ifdef RYDIFF_AUTO_XCD
+        if (rt.variant != 0 || pl.B < 8 || live > budget) return 0;
+#else
+        return 0;
+#endif
+    }
+    const int m = int(std::max<size_t>(1, budget / live));
+    return 8 * m;
+}
+
+}  // namespace
 
 // ------------------------------------------------------------------------------------------------
 // C ABI
@@ -1703,30 +1820,13 @@ void build_persist_table(const Runtime& rt, std::vector<PersistFactor>& table) {
 extern "C" {
 
 const char* rydiff_last_error(void) { return g_last_error.c_str(); }
-const char* rydiff_version(void) { return "rydiff 0.1 (gfx950)"; }
+const char* rydiff_version(void) { return "rydiff 0.2 (gfx950)"; }
 
 #ifdef RYDIFF_TIMELINE
 int rydiff_debug_timeline(unsigned long long* host_buf, int n_entries) {  // tuning builds only
     return hipMemcpyFromSymbol(host_buf, HIP_SYMBOL(g_timeline), size_t(n_entries) * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
 }
 #endif
-
-int rydiff_set_kernel_variant(int variant) {
-    // 0 auto | 1 direct | 2 chained tiles, 512 threads | 3 chained tiles, 256 threads | 4 chained tiles, 1024 threads
-    // 5 single-pass LDS tiles with partner-tile loads (forward / recompute passes; adjoint stays direct)
-    // 6 chained tiles with sub-tile pipelining (13 <= N <= 22; experimental)
-    // 8 LDS-tile persistent kernels also for N <= 6 (A/B reference of the one-wave lane kernels)
-    // 9 direct kernels as 1, but always the generic ones (A/B reference of the unrolled global-drive instantiations)
-    // 7 auto, but three tile layouts wherever they are legal (21 <= N <= 28; default from N = 23)
-    if (variant < 0 || variant > 9) return fail(RYDIFF_EINVAL, "kernel variant must be 0..9");
-    g_generic_direct = variant == 9;
-    if (variant == 9) variant = 1;
-    g_force_three_layouts = variant == 7;
-    if (variant == 7) variant = 0;
-    g_kernel_variant = variant;
-    g_chain_lgt = variant == 3 ? 8 : (variant == 4 ? 10 : 9);
-    return RYDIFF_OK;
-}
 
 int rydiff_design_polynomial(double rho, double tol, int max_degree, int* degree, double* roots_reim, double* p0_reim, double* max_err) {
     if (!(rho > 0.0) || !degree || !roots_reim || max_degree < 1) return fail(RYDIFF_EINVAL, "bad arguments");
@@ -1746,13 +1846,16 @@ int rydiff_design_polynomial(double rho, double tol, int max_degree, int* degree
 }
 
 int rydiff_plan(const RydProblem* p, int need_tape, int need_backward, void* scratch, void* stream_, RydPlanInfo* info) {
+    if (!p) return fail(RYDIFF_EINVAL, "null problem");
     if (!info || !scratch) return fail(RYDIFF_EINVAL, "null info or scratch");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     Runtime rt;
     std::string err;
+    int rc = decode_variant(p, rt);
+    if (rc) return rc;
     if (!build_plan(p, rt.pl, err)) return fail(err.find("not implemented") != std::string::npos ? RYDIFF_ENOTIMPL : RYDIFF_EINVAL, err);
     double lo, hi;
-    int rc = run_stats(p, rt.pl, scratch, stream, lo, hi, rt.flags);
+    rc = run_stats(p, rt.pl, scratch, stream, lo, hi, rt.flags);
     if (rc) return rc;
     if (!build_plan(p, rt.pl, err, generator_half_width(rt.pl, lo, hi))) return fail(RYDIFF_EINVAL, err);
     rc = finish_runtime(rt, lo, hi);
@@ -1798,14 +1901,10 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
     }
     std::vector<ChainItem> chain;
     if (persist_enabled(rt)) {
-        // whole trajectory in one launch; the factor table goes to the (otherwise unused) first ping-pong buffer region
-        std::vector<PersistFactor> table;
-        build_persist_table(rt, table);
-        const size_t tbytes = table.size() * sizeof(PersistFactor);
-        if (tbytes > pl.ptable_bytes) return fail(RYDIFF_EWORKSPACE, "internal: factor table does not fit");
-        PersistFactor* dtab = reinterpret_cast<PersistFactor*>(ws + pl.off_ptable);
-        HIP_TRY(hipMemcpyAsync(dtab, table.data(), tbytes, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
+        // whole trajectory in one launch, from a factor table built on the device
+        int n_factors = 0;
+        rc = build_persist_table_device(rt, ws, stream, &n_factors);
+        if (rc) return rc;
         PersistArgs pa{};
         pa.psi0 = static_cast<const double2*>(psi0);
         pa.states = full_ws_tape ? copy_out : tape;
@@ -1814,8 +1913,8 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
         pa.coef = reinterpret_cast<const double*>(ws + pl.off_coef);
         pa.coef_bstride = pl.Bc > 1 ? long(pl.stages.size()) * pl.NC : 0;
         pa.NC = pl.NC;
-        pa.factors = dtab;
-        pa.n_factors = int(table.size());
+        pa.factors = reinterpret_cast<const PersistFactor*>(ws + pl.off_ptable);
+        pa.n_factors = n_factors;
         pa.obs = want_exp ? obs : nullptr;
         pa.expect = expect_out;
         pa.n_obs = want_exp ? pl.n_obs : 0;
@@ -1830,7 +1929,7 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
             pa.dmask[g] = pl.gd.amp_index_mask[g];
             pa.dcnt[g] = pl.gd.count[g];
         }
-        return (rt.flags & 1) ? launch_persist<true>(pl.N, pa, pl.B, stream) : launch_persist<false>(pl.N, pa, pl.B, stream);
+        return (rt.flags & 1) ? launch_persist<true>(rt.variant, pl.N, pa, pl.B, stream) : launch_persist<false>(rt.variant, pl.N, pa, pl.B, stream);
     }
     if (chain_enabled(rt)) {
         // one chain over the whole run: factor i of step k; complete outputs at step ends go to the tape
@@ -1843,29 +1942,35 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
                 step_of_end.push_back(i + 1 == chain.size() ? k + 1 : 0);
             }
         }
-        int flip = 0;
         const bool full_tape = full_ws_tape;
-        auto dst = [&](int i) -> double2* {
-            if (full_tape) return tape + size_t(i + 1) * sv;  // entry g = output of global factor g (entry 0 = psi0)
-            if (step_of_end[i] && tape) return tape + size_t(step_of_end[i]) * sv;
-            flip ^= 1;
-            return buf[flip];
-        };
-        auto done = [&](int i, const double2* out) -> int {
-            if (copy_out && step_of_end[i])
-                HIP_TRY(hipMemcpyAsync(copy_out + size_t(step_of_end[i]) * sv, out, pl.state_bytes, hipMemcpyDeviceToDevice, stream));
-            return RYDIFF_OK;
-        };
-        auto exp_slot = [&](int i, ChainStep& cs) {
-            if (want_exp && step_of_end[i]) {  // the pass that completes a step's last factor also reduces <O>
-                cs.obs = obs;
-                cs.n_obs = pl.n_obs;
-                cs.exp_ostride = long(pl.T + 1) * pl.B;
-                cs.expect_slot = expect_out + size_t(step_of_end[i]) * pl.B;
-            }
-        };
-        rc = run_chain(rt, ws, all, cur, dst, done, exp_slot, false, stream);
-        if (rc) return rc;
+        const int grp = xcd_group_size(rt);
+        for (int b0 = 0; b0 < pl.B; b0 += (grp ? grp : pl.B)) {
+            const BatchSlice bs{b0, std::min(grp ? grp : pl.B, pl.B - b0), grp > 0};
+            int flip = 0;
+            auto dst = [&](int i) -> double2* {
+                if (full_tape) return tape + size_t(i + 1) * sv;  // entry g = output of global factor g (entry 0 = psi0)
+                if (step_of_end[i] && tape) return tape + size_t(step_of_end[i]) * sv;
+                if (bs.xcd) return buf[0];  // rewritten in place: the trajectory's lines stay in its XCD's L2
+                flip ^= 1;
+                return buf[flip];
+            };
+            auto done = [&](int i, const double2* out) -> int {
+                if (copy_out && step_of_end[i])
+                    HIP_TRY(hipMemcpyAsync(copy_out + size_t(step_of_end[i]) * sv + size_t(bs.first) * pl.dim, out + size_t(bs.first) * pl.dim,
+                                           size_t(bs.count) * pl.dim * sizeof(double2), hipMemcpyDeviceToDevice, stream));
+                return RYDIFF_OK;
+            };
+            auto exp_slot = [&](int i, ChainStep& cs) {
+                if (want_exp && step_of_end[i]) {  // the pass that completes a step's last factor also reduces <O>
+                    cs.obs = obs;
+                    cs.n_obs = pl.n_obs;
+                    cs.exp_ostride = long(pl.T + 1) * pl.B;
+                    cs.expect_slot = expect_out + size_t(step_of_end[i]) * pl.B;
+                }
+            };
+            rc = run_chain(rt, ws, all, cur, dst, done, exp_slot, false, bs, stream);
+            if (rc) return rc;
+        }
         return RYDIFF_OK;
     }
     int pp = 0;
@@ -1895,9 +2000,6 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
             hipLaunchKernelGGL(k_expect_diag, dim3(red_blocks, pl.B), dim3(256), 0, stream, cur, obs, expect_out, pl.n_obs, pl.T + 1, k + 1, pl.B, uint32_t(pl.dim));
             LAUNCH_CHECK();
         }
-    }
-    if (!tape && states_out == nullptr && need_tape == 0) {
-        // nothing else to do: caller only wanted expectation values
     }
     return RYDIFF_OK;
 }
@@ -1929,6 +2031,11 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
     const double2* gst = static_cast<const double2*>(grad_states);
     const double* obs = p->obs_diag;
     const bool have_gexp = grad_expect && pl.n_obs > 0;
+    InjectSource inj{};
+    inj.gstate = gst;
+    inj.gexp = have_gexp ? grad_expect : nullptr;
+    inj.obs = obs;
+    inj.n_obs = have_gexp ? pl.n_obs : 0;
 
     HIP_TRY(hipMemsetAsync(ge, 0, size_t(pl.Bc) * E * ge_rec * sizeof(double), stream));
     if (wtot) HIP_TRY(hipMemsetAsync(wtot, 0, pl.dim * sizeof(double), stream));
@@ -1944,21 +2051,16 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
     }
     auto state_at = [&](int k) -> const double2* { return tape + size_t(full_tape ? fprefix[k] : k) * sv; };
 
-    std::vector<int32_t> inject_at(pl.T + 1, 1);
     // small registers: the whole reverse sweep in one launch (k_persist_bwd)
     // (4096 amplitudes would need 8 per thread plus the accumulators: past the register file, so N = 12 keeps the launch-per-factor sweep)
     const bool persisted = persist_enabled(rt) && pl.N <= kPersistBwdMaxQubits && !full_tape && pl.ga.n <= kPersistGroups &&
                            pl.gd.n <= kPersistGroups &&
                            rt.max_step_factors <= kStageChunk;
     if (persisted) {
-        std::vector<PersistFactor> table;
-        build_persist_table(rt, table);
-        const size_t tbytes = table.size() * sizeof(PersistFactor);
-        if (tbytes > pl.ptable_bytes) return fail(RYDIFF_EWORKSPACE, "internal: factor table does not fit");
+        int n_factors = 0;
+        rc = build_persist_table_device(rt, ws, stream, &n_factors);
+        if (rc) return rc;
         if (rt.max_step_factors - 1 > pl.chain_slots) return fail(RYDIFF_EWORKSPACE, "internal: chain buffers too small");
-        PersistFactor* dtab = reinterpret_cast<PersistFactor*>(ws + pl.off_ptable);
-        HIP_TRY(hipMemcpyAsync(dtab, table.data(), tbytes, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
         int32_t* dflags = nullptr;
         if (have_gexp) {  // stays on the device: the sweep skips save points without an expectation cotangent
             dflags = reinterpret_cast<int32_t*>(ws + pl.off_meta2);
@@ -1977,8 +2079,8 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
         pa.coef = coef;
         pa.coef_bstride = coef_bstride;
         pa.NC = pl.NC;
-        pa.factors = dtab;
-        pa.n_factors = int(table.size());
+        pa.factors = reinterpret_cast<const PersistFactor*>(ws + pl.off_ptable);
+        pa.n_factors = n_factors;
         pa.ge = ge;
         pa.ge_bstride = ge_bstride;
         pa.ge_sstride = ge_rec;
@@ -1997,64 +2099,26 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
             pa.dmask[g] = pl.gd.amp_index_mask[g];
             pa.dcnt[g] = pl.gd.count[g];
         }
-        rc = (rt.flags & 1) ? launch_persist_bwd<true>(pl.N, pa, pl.B, stream) : launch_persist_bwd<false>(pl.N, pa, pl.B, stream);
+        rc = (rt.flags & 1) ? launch_persist_bwd<true>(rt.variant, pl.N, pa, pl.B, stream) : launch_persist_bwd<false>(rt.variant, pl.N, pa, pl.B, stream);
         if (rc) return rc;
     } else {
-        // save points without any cotangent need no injection pass (with only grad_expect given this is decided up front:
-        // one tiny kernel + one copy; the scatter metadata region is free until the end of the sweep)
-        if (!gst && have_gexp) {
-            int32_t* dflags = reinterpret_cast<int32_t*>(ws + pl.off_meta2);
-            hipLaunchKernelGGL(k_cotangent_flags, dim3(unsigned(pl.T + 1 + 255) / 256), dim3(256), 0, stream, grad_expect, pl.n_obs,
-                               pl.T + 1, pl.B, dflags);
-            LAUNCH_CHECK();
-            HIP_TRY(hipMemcpyAsync(inject_at.data(), dflags, size_t(pl.T + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipStreamSynchronize(stream));
-        }
-        // cotangent at the final time
+        // cotangent at the final time; the cotangents of the earlier save points are added by the launch that completes the
+        // adjoint state there (fused injection: no separate launches, and no host-side look at grad_expect)
         hipLaunchKernelGGL(k_inject, grid, dim3(256), 0, stream, lam[cl], gst ? gst + size_t(pl.T) * sv : nullptr,
                            state_at(pl.T), obs, have_gexp ? grad_expect : nullptr, pl.n_obs, pl.T + 1, pl.T, pl.B,
                            uint32_t(pl.dim), 1);
         LAUNCH_CHECK();
     }
 
-    std::vector<ChainItem> chain;
-    std::vector<const double2*> xs;
-    std::vector<ChainItem> part;
-    for (int k = persisted ? -1 : pl.T - 1; k >= 0; --k) {
-        // With every factor input on the tape, consecutive intervals whose common save point receives no cotangent run as
-        // ONE chain: the launch that finishes the adjoint of interval k's first factor also starts interval k-1's last one.
-        const int k_hi = k;
-        if (full_tape && chain_enabled(rt)) {
-            while (k > 0 && !((gst || have_gexp) && inject_at[k]) && fprefix[k_hi + 1] - fprefix[k - 1] < (int64_t(1) << 16)) --k;
-        }
-        chain.clear();
-        for (int kk = k; kk <= k_hi; ++kk) {
-            build_step_chain(rt, kk, part);
-            chain.insert(chain.end(), part.begin(), part.end());
-        }
-        const int M = int(chain.size());
-        if (!full_tape && M - 1 > pl.chain_slots) return fail(RYDIFF_EWORKSPACE, "internal: chain buffers too small");
-        // recompute the factor inputs x_0 .. x_{M-1}
-        xs.assign(M + 1, nullptr);
-        xs[0] = state_at(k);
-        if (full_tape) {
-            for (int i = 1; i < M; ++i) xs[i] = tape + size_t(fprefix[k] + i) * sv;  // every factor input is on the tape
-        } else if (chain_enabled(rt) && M > 1) {
-            for (int i = 1; i < M; ++i) xs[i] = chainbuf + size_t(i - 1) * sv;
-            auto dst = [&](int i) -> double2* { return chainbuf + size_t(i) * sv; };
-            auto done = [&](int, const double2*) -> int { return RYDIFF_OK; };
-            auto no_exp = [&](int, ChainStep&) {};
-            rc = run_chain(rt, ws, chain, xs[0], dst, done, no_exp, true, stream);
-            if (rc) return rc;
-        } else {
-            for (int i = 1; i < M; ++i) {
-                double2* dst = chainbuf + size_t(i - 1) * sv;
-                rc = launch_factor(rt, ws, xs[i - 1], dst, chain[i - 1].stage, chain[i - 1].s, stream);
-                if (rc) return rc;
-                xs[i] = dst;
-            }
-        }
-        xs[M] = state_at(k_hi + 1);
+    const bool chained = chain_enabled(rt);
+    const int grp = (!persisted && chained) ? xcd_group_size(rt) : 0;
+    const int cl0 = cl;
+    auto sweep = [&](const BatchSlice& bs) -> int {
+        std::vector<ChainItem> chain, part;
+        std::vector<const double2*> xs;
+        std::vector<int> save_k;
+        cl = cl0;
+        const dim3 grid_s(grid.x, unsigned(bs.count));
         auto dot_h = [&](int stage, const double2* g, const double2* xout) -> int {
             if (!g_tsave) return RYDIFF_OK;
             DotHArgs da{};
@@ -2067,75 +2131,112 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
             da.out_bstride = ge_bstride;
             da.out_rstride = pl.NC + 1;
             da.dim = uint32_t(pl.dim);
+            da.b_first = bs.first;
             da.gr = rt.garg;
             da.pair = rt.parg;
-            hipLaunchKernelGGL(k_dot_hx, grid, dim3(256), 0, stream, da);
+            hipLaunchKernelGGL(k_dot_hx, grid_s, dim3(256), 0, stream, da);
             LAUNCH_CHECK();
             return RYDIFF_OK;
         };
-        if (chain_enabled(rt)) {
-            rc = run_chain_bwd(rt, ws, chain, xs, lam[cl], lam, cl, wtot, dot_h, stream);
-            if (rc) return rc;
-        } else
-        for (int i = M; i >= 1; --i) {
-            const ChainItem& it = chain[i - 1];
-            // dL/dtau of an exponential is taken at its output (end of its last factor)
-            const bool stage_end = (i == M) || (chain[i].stage != it.stage);
-            if (g_tsave && stage_end) {
-                DotHArgs da{};
-                da.g = lam[cl];
-                da.x = xs[i];
-                da.udiag = udiag;
-                da.coef = coef + size_t(it.stage) * pl.NC;
-                da.coef_bstride = coef_bstride;
-                da.out = ge + size_t(it.stage) * ge_rec + pl.NC;
-                da.out_bstride = ge_bstride;
-                da.out_rstride = pl.NC + 1;
-                da.dim = uint32_t(pl.dim);
-                da.gr = rt.garg;
-            da.pair = rt.parg;
-                hipLaunchKernelGGL(k_dot_hx, grid, dim3(256), 0, stream, da);
-                LAUNCH_CHECK();
+        for (int k = pl.T - 1; k >= 0; --k) {
+            // With every factor input on the tape, consecutive intervals run as ONE chain: the launch that finishes the adjoint
+            // of interval k's first factor (and adds the cotangent injected at save point k) also starts interval k-1's last one.
+            const int k_hi = k;
+            if (full_tape && chained) {
+                while (k > 0 && fprefix[k_hi + 1] - fprefix[k - 1] < (int64_t(1) << 16)) --k;
             }
-            FactorBwdArgs ba{};
-            ba.gin = lam[cl];
-            ba.xin = xs[i - 1];
-            ba.gout = lam[cl ^ 1];
-            ba.udiag = udiag;
-            ba.coef = coef + size_t(it.stage) * pl.NC;
-            ba.coef_bstride = coef_bstride;
-            ba.ge = ge + size_t(it.stage) * ge_rec;
-            ba.ge_bstride = ge_bstride;
-            ba.ge_rstride = pl.NC + 1;
-            ba.wtot = wtot;
-            ba.dim = uint32_t(pl.dim);
-            ba.gr = it.s.gr;
-            ba.gi = it.s.gi;
-            ba.br = it.s.br;
-            ba.bi = it.s.bi;
-            ba.g = rt.garg;
-            ba.pair = rt.parg;
-            if (direct_global_ok(pl)) {
-                const dim3 grid8(grid.x * 8, grid.y);
-                switch (pl.N) {
+            chain.clear();
+            save_k.clear();
+            for (int kk = k; kk <= k_hi; ++kk) {
+                build_step_chain(rt, kk, part);
+                for (size_t i = 0; i < part.size(); ++i) save_k.push_back(i == 0 ? kk : -1);
+                chain.insert(chain.end(), part.begin(), part.end());
+            }
+            const int M = int(chain.size());
+            if (!full_tape && M - 1 > pl.chain_slots) return fail(RYDIFF_EWORKSPACE, "internal: chain buffers too small");
+            // the factor inputs x_0 .. x_{M-1}: on the tape, or recomputed
+            xs.assign(M + 1, nullptr);
+            xs[0] = state_at(k);
+            if (full_tape) {
+                for (int i = 1; i < M; ++i) xs[i] = tape + size_t(fprefix[k] + i) * sv;  // every factor input is on the tape
+            } else if (chained && M > 1) {
+                for (int i = 1; i < M; ++i) xs[i] = chainbuf + size_t(i - 1) * sv;
+                auto dst = [&](int i) -> double2* { return chainbuf + size_t(i) * sv; };
+                auto done = [&](int, const double2*) -> int { return RYDIFF_OK; };
+                auto no_exp = [&](int, ChainStep&) {};
+                int rc2 = run_chain(rt, ws, chain, xs[0], dst, done, no_exp, true, bs, stream);
+                if (rc2) return rc2;
+            } else {
+                for (int i = 1; i < M; ++i) {
+                    double2* dst = chainbuf + size_t(i - 1) * sv;
+                    int rc2 = launch_factor(rt, ws, xs[i - 1], dst, chain[i - 1].stage, chain[i - 1].s, stream);
+                    if (rc2) return rc2;
+                    xs[i] = dst;
+                }
+            }
+            xs[M] = state_at(k_hi + 1);
+            if (chained) {
+                int rc2 = run_chain_bwd(rt, ws, chain, xs, save_k, lam[cl], lam, cl, wtot, dot_h, bs, inj, stream);
+                if (rc2) return rc2;
+                continue;
+            }
+            for (int i = M; i >= 1; --i) {
+                const ChainItem& it = chain[i - 1];
+                // dL/dtau of an exponential is taken at its output (end of its last factor)
+                const bool stage_end = (i == M) || (chain[i].stage != it.stage);
+                if (stage_end) {
+                    int rc2 = dot_h(it.stage, lam[cl], xs[i]);
+                    if (rc2) return rc2;
+                }
+                FactorBwdArgs ba{};
+                ba.gin = lam[cl];
+                ba.xin = xs[i - 1];
+                ba.gout = lam[cl ^ 1];
+                ba.udiag = udiag;
+                ba.coef = coef + size_t(it.stage) * pl.NC;
+                ba.coef_bstride = coef_bstride;
+                ba.ge = ge + size_t(it.stage) * ge_rec;
+                ba.ge_bstride = ge_bstride;
+                ba.ge_rstride = pl.NC + 1;
+                ba.wtot = wtot;
+                ba.dim = uint32_t(pl.dim);
+                ba.gr = it.s.gr;
+                ba.gi = it.s.gi;
+                ba.br = it.s.br;
+                ba.bi = it.s.bi;
+                ba.g = rt.garg;
+                ba.pair = rt.parg;
+                if (save_k[i - 1] >= 0 && inj.any()) {  // gout is the cotangent at save point k: add what is injected there
+                    const int ks = save_k[i - 1];
+                    ba.inj_gstate = inj.gstate ? inj.gstate + size_t(ks) * sv : nullptr;
+                    ba.inj_gexp = inj.gexp ? inj.gexp + size_t(ks) * pl.B : nullptr;
+                    ba.inj_obs = inj.obs;
+                    ba.inj_n_obs = inj.n_obs;
+                    ba.inj_ostride = long(pl.T + 1) * pl.B;
+                }
+                if (direct_global_ok(rt)) {
+                    const dim3 grid8(grid.x * 8, grid.y);
+                    switch (pl.N) {
 #define RYDIFF_CASE1(NQ) case NQ: hipLaunchKernelGGL((k_factor_bwd_direct_global<NQ, true>), grid8, dim3(256), 0, stream, ba); break;
 #define RYDIFF_CASE(NQ) case NQ: hipLaunchKernelGGL((k_factor_bwd_direct_global<NQ, false>), grid, dim3(256), 0, stream, ba); break;
-                    RYDIFF_CASE1(12) RYDIFF_CASE1(13)
-                    RYDIFF_CASE(14) RYDIFF_CASE(15) RYDIFF_CASE(16) RYDIFF_CASE(17) RYDIFF_CASE(18) RYDIFF_CASE(19) RYDIFF_CASE(20)
+                        RYDIFF_CASE1(12) RYDIFF_CASE1(13)
+                        RYDIFF_CASE(14) RYDIFF_CASE(15) RYDIFF_CASE(16) RYDIFF_CASE(17) RYDIFF_CASE(18) RYDIFF_CASE(19) RYDIFF_CASE(20)
 #undef RYDIFF_CASE
 #undef RYDIFF_CASE1
+                    }
+                } else {
+                    hipLaunchKernelGGL(k_factor_bwd_direct, grid, dim3(256), 0, stream, ba);
                 }
-            } else {
-                hipLaunchKernelGGL(k_factor_bwd_direct, grid, dim3(256), 0, stream, ba);
+                LAUNCH_CHECK();
+                cl ^= 1;
             }
-            LAUNCH_CHECK();
-            cl ^= 1;
         }
-        if ((gst || have_gexp) && inject_at[k]) {
-            hipLaunchKernelGGL(k_inject, grid, dim3(256), 0, stream, lam[cl], gst ? gst + size_t(k) * sv : nullptr,
-                               state_at(k), obs, have_gexp ? grad_expect : nullptr, pl.n_obs, pl.T + 1, k, pl.B,
-                               uint32_t(pl.dim), 0);
-            LAUNCH_CHECK();
+        return RYDIFF_OK;
+    };
+    if (!persisted) {
+        for (int b0 = 0; b0 < pl.B; b0 += (grp ? grp : pl.B)) {
+            rc = sweep(BatchSlice{b0, std::min(grp ? grp : pl.B, pl.B - b0), grp > 0});
+            if (rc) return rc;
         }
     }
     if (g_psi0) HIP_TRY(hipMemcpyAsync(g_psi0, lam[cl], pl.state_bytes, hipMemcpyDeviceToDevice, stream));
@@ -2145,32 +2246,21 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
     if (g_det) HIP_TRY(hipMemsetAsync(g_det, 0, size_t(pl.Bc) * pl.Kd * pl.n_samples * 8, stream));
     if (g_tsave) HIP_TRY(hipMemsetAsync(g_tsave, 0, size_t(pl.T + 1) * 8, stream));
     if ((g_amp && pl.Ka) || (g_det && pl.Kd) || g_tsave) {
-        // extra metadata (dwdt, tinfo, tscale) lives at the start of the chain region, which is free now
-        std::vector<double> dwdt(E * 4), tscale(E * 3);
-        std::vector<int32_t> tinfo(E * 4);
-        for (size_t e = 0; e < E; ++e) {
-            for (int q = 0; q < 4; ++q) dwdt[e * 4 + q] = pl.stages[e].dwdt[q];
-            tinfo[e * 4] = pl.stages[e].tn[0];
-            tinfo[e * 4 + 1] = pl.stages[e].tn[1];
-            tinfo[e * 4 + 2] = pl.stages[e].t_hi;
-            tinfo[e * 4 + 3] = pl.stages[e].t_lo;
-            tscale[e * 3] = pl.stages[e].tau_scale;
-            tscale[e * 3 + 1] = pl.stages[e].tnw[0];
-            tscale[e * 3 + 2] = pl.stages[e].tnw[1];
+        char* m = ws + pl.off_meta2;  // (the save-point flags of the one-launch adjoint, which share the region, are dead by now)
+        if (g_tsave) {
+            std::vector<StageBwdDev> sb(E);
+            for (size_t e = 0; e < E; ++e) {
+                const Stage& st = pl.stages[e];
+                sb[e] = {st.tau_scale, st.tnw[0], st.tnw[1], st.tn[0], st.tn[1], st.t_hi, st.t_lo};
+            }
+            rc = upload_words(stream, m, sb.data(), E * sizeof(StageBwdDev));
+            if (rc) return rc;
         }
-        char* m = ws + pl.off_meta2;
-        const size_t o1 = align_up(E * 4 * sizeof(double)), o2 = o1 + align_up(E * 4 * sizeof(int32_t));
-        HIP_TRY(hipMemcpyAsync(m, dwdt.data(), dwdt.size() * sizeof(double), hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(m + o1, tinfo.data(), tinfo.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(m + o2, tscale.data(), tscale.size() * sizeof(double), hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
         ScatterArgs sa{};
         sa.ge = ge;
-        sa.idx = reinterpret_cast<const int32_t*>(ws + pl.off_meta_idx);
-        sa.w = reinterpret_cast<const double*>(ws + pl.off_meta_w);
-        sa.dwdt = reinterpret_cast<const double*>(m);
-        sa.tinfo = reinterpret_cast<const int32_t*>(m + o1);
-        sa.tscale = reinterpret_cast<const double*>(m + o2);
+        sa.st = reinterpret_cast<const StageDev*>(ws + pl.off_meta_idx);
+        sa.sb = reinterpret_cast<const StageBwdDev*>(m);
+        sa.inv_dt = pl.dt > 0.0 ? 1.0 / pl.dt : 0.0;
         sa.amp = static_cast<const double2*>(p->amp_tables);
         sa.det = p->det_tables;
         sa.g_amp = static_cast<double2*>(g_amp);
@@ -2204,7 +2294,10 @@ int rydiff_apply_factor(const RydProblem* p, const double* c_amp_reim, const dou
                         const double* beta_reim, const void* x, void* y, int n_remote, const void* const* remote,
                         const double* remote_coef_reim, int reuse_diag, void* workspace, size_t workspace_bytes, void* stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!p) return fail(RYDIFF_EINVAL, "null problem");
     if (!x || !y || !workspace || !gamma_reim || !beta_reim) return fail(RYDIFF_EINVAL, "null buffer");
+    if ((p->n_amp_terms > 0 && !c_amp_reim) || (p->n_det_terms > 0 && !c_det))
+        return fail(RYDIFF_EINVAL, "missing coefficient values (c_amp_reim / c_det) for the problem's terms");
     if (n_remote < 0 || n_remote > kMaxRemote || (n_remote > 0 && (!remote || !remote_coef_reim)))
         return fail(RYDIFF_EINVAL, "bad remote vector list");
     RydProblem q = *p;

@@ -53,6 +53,8 @@ class ProblemSpec:
     options: dict = field(default_factory=dict)
     # dense two-qubit terms of the generator (include/rydiff.h): ((qubit_a, qubit_b, 4x4 complex table), ...); constants
     pair_terms: tuple = ()
+    # kernel family (RydProblem.kernel_variant): None = this thread's default (_native.set_kernel_variant, normally 0 = automatic)
+    kernel_variant: Optional[int] = None
 
     def solver_code(self) -> int:
         if self.solver not in _SOLVER_CODE:
@@ -123,7 +125,32 @@ class _Call:
         p.pair_qubits = self.pair_qubits.ctypes.data if spec.pair_terms else None
         p.pair_tables = self.pair_tables.ctypes.data if spec.pair_terms else None
         p.real_amp_grad = int(real_amp_grad)  # the caller's amplitude tables are a REAL tensor: only Re(g_amp) is used
+        p.kernel_variant = _native.default_kernel_variant() if spec.kernel_variant is None else int(spec.kernel_variant)
         self.problem = p
+
+
+def _check_shapes(spec: ProblemSpec, amp: Tensor, det: Tensor, u_pairs: Tensor, obs: Optional[Tensor], batch: int) -> None:
+    """The C ABI sees raw pointers only: every buffer is checked against the spec here, so that a mismatch is a ValueError and
+    never an out-of-bounds device read."""
+    ka, kd, n, nq = len(spec.amp_masks), len(spec.det_masks), spec.n_samples, spec.n_qubits
+    cb = None
+    for name, t, k in (("amp_tables", amp, ka), ("det_tables", det, kd)):
+        if k == 0:
+            continue
+        if t.ndim != 3 or t.shape[1] != k or t.shape[2] != n:
+            raise ValueError(f"{name} must have shape (coeff_batch, {k}, {n}), got {tuple(t.shape)}")
+        if t.shape[0] not in (1, batch):
+            raise ValueError(f"{name}: coeff_batch must be 1 or the batch size {batch}, got {t.shape[0]}")
+        if cb is not None and t.shape[0] != cb:
+            raise ValueError(f"amp_tables and det_tables disagree on coeff_batch ({cb} vs {t.shape[0]})")
+        cb = t.shape[0]
+    n_pairs = nq * (nq - 1) // 2
+    if u_pairs.numel() != n_pairs:
+        raise ValueError(f"u_pairs must hold N(N-1)/2 = {n_pairs} values, got {u_pairs.numel()}")
+    if obs is not None and obs.numel() and (obs.ndim != 2 or obs.shape[1] != 2 ** nq):
+        raise ValueError(f"obs_diag must have shape (n_obs, {2 ** nq}), got {tuple(obs.shape)}")
+    if batch > 65535:
+        raise ValueError("batch must be <= 65535 (split the columns / trajectories into several calls)")
 
 
 def _stream_ptr(device: torch.device) -> ctypes.c_void_p:
@@ -150,9 +177,12 @@ class _RydbergEvolve(torch.autograd.Function):
         psi_c = psi0.detach().to(torch.complex128).contiguous()
         obs_c = None if obs is None else obs.detach().to(torch.float64).contiguous()
         ts_host = tsave.detach().to("cpu", torch.float64).numpy()
+        if psi_c.ndim != 2:
+            raise ValueError(f"psi0 must be (batch, 2^N), got shape {tuple(psi_c.shape)}")
         batch, dim = psi_c.shape
         if dim != 2 ** spec.n_qubits:
             raise ValueError(f"Incompatible shape of initial state.Expected {2 ** spec.n_qubits}, got {dim}.")
+        _check_shapes(spec, amp_c, det_c, u_c, obs_c, batch)
         n_t = len(ts_host)
         call = _Call(spec, amp_c, det_c, u_c, ts_host, batch, obs_c)
         needs_grad = any(ctx.needs_input_grad[:5])
