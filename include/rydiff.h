@@ -133,6 +133,9 @@ typedef struct RydPlanInfo {
     size_t workspace_bytes;          /* device workspace needed by forward/backward for the flags given to rydiff_plan */
     int32_t tape_mode;               /* the tape the workspace was sized for: 0 none, 1 one state per tsave, 2 full (need_tape = 2
                                         is granted only where the chained tile passes will run) */
+    int32_t kernel_family;           /* which forward kernels the problem will run on (reporting only): 0 one-wave lane sweep
+                                        (<= 6 qubits), 1 one-workgroup persistent sweep (<= 12 qubits), 2 direct launch per factor,
+                                        3 chained LDS-tile launch per factor */
 } RydPlanInfo;
 
 #define RYDIFF_PLAN_SCRATCH_BYTES 1024

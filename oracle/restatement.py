@@ -473,6 +473,99 @@ def krylov_map_matrix_free(terms: HamTerms, psi0: np.ndarray, tsave: np.ndarray,
     return np.stack(out)
 
 
+# ---- the same map, matrix-free AND differentiable (torch): gradient goldens for registers too large for dense H --------
+def _bit_masks_torch(n: int) -> list[Tensor]:
+    x = torch.arange(2**n)
+    return [((x >> (n - 1 - j)) & 1).to(RDTYPE) for j in range(n)]
+
+
+class _FlipSums(torch.autograd.Function):
+    """tall[x] = sum_{j in targets} psi[x ^ m_j],  t1[x] = sum_{j in targets} bit_j(x) psi[x ^ m_j]: real-linear maps with constant
+    structure, so nothing is kept for the backward pass (adjoints: tall^T = tall, t1^T g = sum_j flip_j(bit_j g))."""
+
+    @staticmethod
+    def forward(ctx, psi, n, targets, masks):
+        ctx.meta = (n, targets, masks)
+        shape = (2,) * n + tuple(psi.shape[1:])
+        tail = (1,) * (psi.ndim - 1)
+        t1 = torch.zeros_like(psi)
+        tall = torch.zeros_like(psi)
+        for j in targets:
+            fl = torch.flip(psi.reshape(shape), dims=(j,)).reshape(psi.shape)
+            tall += fl
+            t1 += masks[j].reshape((-1,) + tail) * fl
+        return t1, tall
+
+    @staticmethod
+    def backward(ctx, g1, gall):
+        n, targets, masks = ctx.meta
+        shape = (2,) * n + tuple(g1.shape[1:])
+        tail = (1,) * (g1.ndim - 1)
+        out = torch.zeros_like(g1)
+        for j in targets:
+            out += torch.flip((masks[j].reshape((-1,) + tail) * g1 + gall).reshape(shape), dims=(j,)).reshape(g1.shape)
+        return out, None, None, None
+
+
+def structured_matvec_torch(terms: HamTerms, diag: Tensor, coeffs: list, psi: Tensor, masks: list[Tensor]) -> Tensor:
+    """(H psi)[x] = diag[x] psi[x] + sum_terms sum_{j in targets} (c if bit_j(x) = 1 else conj(c)) psi[x ^ m_j]
+    (hamiltonian.py:536-544) on a (2^N,) or (2^N, B) tensor, with torch ops only so that autograd
+    differentiates it.  `coeffs`: [(c, targets)] already interpolated.  Only the products with c / diag keep tensors alive
+    for the backward pass (the flips are linear maps with constant structure: _FlipSums)."""
+    n = terms.n_qubits
+    tail = (1,) * (psi.ndim - 1)
+    out = diag.reshape((-1,) + tail) * psi
+    for c, targets in coeffs:
+        t1, tall = _FlipSums.apply(psi, n, tuple(targets), masks)  # t1: partners seen from rows with bit_j = 1 (row g: <g|H|r> = c)
+        out = out + c * t1 + torch.conj(c) * (tall - t1)
+    return out
+
+
+def krylov_map_matrix_free_torch(terms: HamTerms, psi0: Tensor, tsave: Tensor, tol: float = 1e-17,
+                                 checkpoint: bool = False) -> Tensor:
+    """Same map as krylov_map_dense — psi_{k+1} = exp(-i H(t_{k+1}) (t_{k+1} - t_k)) psi_k — evaluated matrix-free by the
+    Taylor series of the exponential (terms until below `tol` relative), in torch: autograd through it gives the exact
+    gradients of the discrete map w.r.t. the coefficient arrays, U_ij, tsave and psi0 for registers far beyond dense H.
+    A different numerical route from the product-form Chebyshev polynomial of the native library and from Lanczos.
+    psi0: (dim,) or (dim, B).  checkpoint=True re-computes each step in the backward pass (memory of one step)."""
+    n = terms.n_qubits
+    masks = _bit_masks_torch(n)
+    occ = occupation_table(n)
+    udiag = interaction_diagonal(n, terms.u_pairs)
+
+    def step(psi, t_hi, t_lo, udiag_, *flat):
+        amp_c = flat[:len(terms.amp_terms())]
+        det_c = flat[len(terms.amp_terms()):]
+        diag = udiag_
+        for (_, tg), coeff in zip(terms.det_terms(), det_c):
+            d = interp_coeff(coeff, t_hi, terms.dt, terms.n_samples)
+            diag = diag + 2.0 * d * sum(occ[j] for j in tg)
+        coeffs = [(interp_coeff(coeff, t_hi, terms.dt, terms.n_samples), tg) for (_, tg), coeff in zip(terms.amp_terms(), amp_c)]
+        tau = t_hi - t_lo
+        term = psi
+        acc = psi
+        ref = float(torch.linalg.vector_norm(psi.detach()))
+        for k in range(1, 200):
+            term = structured_matvec_torch(terms, diag, coeffs, term, masks) * (-1j * tau / k)
+            acc = acc + term
+            if float(torch.linalg.vector_norm(term.detach())) < tol * ref:
+                break
+        return acc
+
+    flat = [c for c, _ in terms.amp_terms()] + [c for c, _ in terms.det_terms()]
+    psi = psi0
+    out = [psi]
+    for k in range(len(tsave) - 1):
+        if checkpoint:
+            from torch.utils.checkpoint import checkpoint as ckpt
+
+            psi = ckpt(step, psi, tsave[k + 1], tsave[k], udiag, *flat, use_reentrant=False)
+        else:
+            psi = step(psi, tsave[k + 1], tsave[k], udiag, *flat)
+        out.append(psi)
+    return torch.stack(out)
+
+
 # Dormand-Prince 5(4) tableau (pyqtorch DP5_SE restated: adaptive, RHS -i H(t) psi)
 _DP_C = [0.0, 1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0]
 _DP_A = [

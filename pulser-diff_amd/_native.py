@@ -24,6 +24,7 @@ RYDIFF_ENOTIMPL = -4
 SOLVER_KRYLOV_SE = 0
 SOLVER_DP5_SE = 1
 PLAN_SCRATCH_BYTES = 1024
+KERNEL_FAMILIES = ("lanes", "persistent", "direct", "chained-tiles")
 MAX_QUBITS = 30
 MAX_TERMS = 64
 
@@ -68,6 +69,7 @@ class RydPlanInfo(ctypes.Structure):
         ("total_factors", ctypes.c_int64),
         ("workspace_bytes", ctypes.c_size_t),
         ("tape_mode", ctypes.c_int32),
+        ("kernel_family", ctypes.c_int32),
     ]
 
 

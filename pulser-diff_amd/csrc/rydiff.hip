@@ -1865,6 +1865,9 @@ int rydiff_plan(const RydProblem* p, int need_tape, int need_backward, void* scr
     const size_t ws = carve(rt.pl, tm, need_backward != 0, std::max(rt.max_step_factors - 1, 1), rt.total_factors);
     fill_info(rt, lo, hi, ws, info);
     info->tape_mode = tm;
+    rt.prefer_direct = few_tiles(rt, need_backward != 0 || tm != 0);
+    if (persist_enabled(rt)) info->kernel_family = lanes_enabled(rt.variant, rt.pl.N, rt.pl.ga.n, rt.pl.gd.n, rt.pl.n_pair) ? 0 : 1;
+    else info->kernel_family = chain_enabled(rt) ? 3 : 2;
     return RYDIFF_OK;
 }
 

@@ -134,8 +134,8 @@ class ShardedProblem:
                         per_q[q] += 2.0 * self.det_tables[k]
             dpos = float(np.clip(per_q, 0, None).sum(0).max())
             dneg = float(np.clip(-per_q, 0, None).sum(0).max())
-        usum = float(np.abs(self.u_pairs).sum())
-        return -(dneg + flip), usum + dpos + flip
+        upos, uneg = float(np.clip(self.u_pairs, 0, None).sum()), float(np.clip(-self.u_pairs, 0, None).sum())
+        return -(uneg + dneg + flip), upos + dpos + flip
 
 
 @dataclass

@@ -203,7 +203,9 @@ class _RydbergEvolve(torch.autograd.Function):
                 if fits and (need_tape or info.tape_mode == 2):
                     need_tape = 2
             if need_tape != 2:
-                _native.check(L.rydiff_plan(ctypes.byref(call.problem), need_tape, need_tape, _ptr(scratch),
+                # a differentiated run is planned WITH the backward-sweep buffers: the backward call then reuses this plan
+                # (rydiff_plan holds the library's only stream synchronisation)
+                _native.check(L.rydiff_plan(ctypes.byref(call.problem), need_tape, int(needs_grad), _ptr(scratch),
                                             stream, ctypes.byref(info)))
             workspace = torch.empty(info.workspace_bytes, dtype=torch.uint8, device=dev)
             states = (torch.empty((n_t, batch, dim), dtype=torch.complex128, device=dev) if spec.store_states
@@ -228,7 +230,8 @@ class _RydbergEvolve(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.stats = {"degree": info.degree, "total_factors": info.total_factors, "rho": info.rho_design,
                      "spectral": (info.spectral_lo, info.spectral_hi), "n_stages": info.n_stages,
-                     "tape": ("none", "steps", "full")[min(need_tape, info.tape_mode) if need_tape else 0]}
+                     "tape": ("none", "steps", "full")[min(need_tape, info.tape_mode) if need_tape else 0],
+                     "kernel_family": _native.KERNEL_FAMILIES[info.kernel_family]}
         spec.options["_last_stats"] = ctx.stats
         return states, expect
 
@@ -261,12 +264,7 @@ class _RydbergEvolve(torch.autograd.Function):
                 workspace = ctx.tape_workspace  # sized for forward + backward by the forward call
                 states_ptr = None
             else:
-                scratch = torch.empty(_native.PLAN_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
-                info_b = _native.RydPlanInfo()
-                _native.check(L.rydiff_plan(ctypes.byref(call.problem), 0, 1, _ptr(scratch), stream,
-                                            ctypes.byref(info_b)))
-                workspace = torch.empty(info_b.workspace_bytes, dtype=torch.uint8, device=dev)
-                info = info_b
+                workspace = torch.empty(info.workspace_bytes, dtype=torch.uint8, device=dev)  # sized by the forward call's plan
                 states_ptr = _ptr(states)
             _native.check(L.rydiff_backward(ctypes.byref(call.problem), ctypes.byref(info), states_ptr, _ptr(g_states),
                                             _ptr(g_expect) if (g_expect is not None and obs is not None) else None,

@@ -91,3 +91,23 @@ def magnus_cf4_dense(terms, psi0, tsave, h_max=2.5e-3):
                     psi = torch.linalg.matrix_exp(-1j * h * (hf / (2.0 * S))) @ psi
         out.append(psi)
     return torch.stack(out)
+
+
+def pack_terms(terms: R.HamTerms) -> dict:
+    """HamTerms -> plain arrays (golden fixtures store their inputs next to the expected outputs)."""
+    amp_terms, det_terms = terms.amp_terms(), terms.det_terms()
+    return {"n_qubits": terms.n_qubits, "dt": terms.dt, "n_samples": terms.n_samples, "u_pairs": terms.u_pairs.detach().numpy(),
+            "amp_tables": torch.stack([c.detach().to(torch.complex128) for c, _ in amp_terms]).numpy(),
+            "det_tables": torch.stack([c.detach().to(torch.float64) for c, _ in det_terms]).numpy(),
+            "amp_masks": np.array([mask_of(tg) for _, tg in amp_terms], dtype=np.int64),
+            "det_masks": np.array([mask_of(tg) for _, tg in det_terms], dtype=np.int64)}
+
+
+def unpack_terms(d) -> R.HamTerms:
+    """Inverse of pack_terms (every term becomes an `extra` term with its own target list)."""
+    n = int(d["n_qubits"])
+    targets = lambda m: [q for q in range(n) if int(m) >> q & 1]  # noqa: E731
+    t = R.HamTerms(n, torch.as_tensor(d["u_pairs"]), None, None, float(d["dt"]), int(d["n_samples"]))
+    t.extra_amp = [(torch.as_tensor(c), targets(m)) for c, m in zip(d["amp_tables"], d["amp_masks"])]
+    t.extra_det = [(torch.as_tensor(c), targets(m)) for c, m in zip(d["det_tables"], d["det_masks"])]
+    return t

@@ -57,6 +57,26 @@ def test_density_matrices_match_the_dense_lindblad_solution(cuda_device, n_qubit
     assert stats["n_stages"] >= len(tsave) - 1
 
 
+def test_strongly_interacting_register_keeps_the_master_equation_accuracy(cuda_device):
+    """5 um spacing (U ~ 350 rad/us).  The doubled register carries +U_ij on the row qubits and -U_ij on the column
+    qubits; the spectral bound has to cover [-sum U, +sum U] or the product-form polynomial is evaluated outside its design
+    interval.  Same 1e-8 bar as the weakly interacting cases."""
+    n_qubits = 3
+    noise = {"dephasing": 0.8, "relaxation": 0.3}
+    terms = random_terms(n_qubits, 21, 0.004, seed=611, local=True, spacing=5.0)
+    assert float(terms.u_pairs.max()) > 200.0
+    tsave = torch.tensor([0.0, 0.0093, 0.031, 0.052, 0.08], dtype=torch.float64)
+    psi0 = torch.randn(2**n_qubits, 1, generator=torch.Generator().manual_seed(5), dtype=torch.complex128)
+    psi0 = psi0 / psi0.norm()
+    cfg = SimConfig(noise=tuple(noise), dephasing_rate=noise["dephasing"], relaxation_rate=noise["relaxation"])
+    rho, _ = mesolve(_ham_like(terms, cuda_device), psi0.to(cuda_device), tsave, cfg.to_noise_model())
+    ref = R.lindblad_continuous_solution(terms, R.collapse_operators(n_qubits, noise), torch.outer(psi0[:, 0], psi0[:, 0].conj()).numpy(),
+                                         tsave.numpy())
+    got = rho[..., 0].cpu().numpy()
+    assert np.abs(got - ref).max() < 1e-8
+    assert np.abs(np.trace(got, axis1=1, axis2=2) - 1.0).max() < 1e-9
+
+
 def test_gradients_through_the_master_equation_match_dense_autograd(cuda_device):
     n = 2
     terms = random_terms(n, 17, 0.004, seed=77, local=True)

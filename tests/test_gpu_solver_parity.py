@@ -246,9 +246,7 @@ def _run_variant(variant, terms, tsave, psi_bd, device, obs, grads=True, batch_t
 
 
 @pytest.mark.parametrize("n_qubits,local,variant", [(13, True, 2), (14, False, 3), (16, True, 4), (17, True, 2), (20, False, 2),
-                                                     (13, True, 5), (18, True, 5), (20, False, 5),
-                                                     (13, True, 6), (16, False, 6), (17, True, 6), (20, True, 6), (22, False, 6),
-                                                     (21, True, 7), (22, True, 7), (23, True, 0), (24, False, 0), (25, True, 0)])
+                                                     (22, False, 4), (21, True, 7), (22, True, 7), (23, True, 0), (24, False, 0), (25, True, 0)])
 def test_chained_tile_kernels_match_direct_kernels(cuda_device, n_qubits, local, variant):
     """A/B on the GPU: the chained LDS-tile kernels (two tile layouts up to 22 qubits, three from 23 — variant 7 forces
     three wherever legal) against the one-amplitude-per-thread kernels (which are themselves pinned to the oracle
@@ -265,6 +263,37 @@ def test_chained_tile_kernels_match_direct_kernels(cuda_device, n_qubits, local,
     assert np.abs((got["expect"] - ref["expect"]).cpu().numpy()).max() < 1e-10
     for key in ("amp", "det", "u"):
         assert rel_err(got[key].cpu().numpy(), ref[key].cpu().numpy()) < 1e-10, key
+
+
+@pytest.mark.parametrize("n_qubits,batch,store", [(13, 11, True), (14, 19, False), (16, 9, False), (17, 3, True)])
+def test_xcd_placement_changes_speed_only(cuda_device, n_qubits, batch, store):
+    """Trajectory-per-XCD placement of the chained tiles (variant 10: groups of 8 m trajectories per launch, vectors rewritten
+    in place with plain loads / stores so that they stay in the XCD's L2) against the plain grid (variant 2): ragged batches,
+    one table set per trajectory, states (or the workspace tape), expectation values at every save point, gradients."""
+    from pulser_diff_amd.solver import SolverType, evolve
+
+    terms = random_terms(n_qubits, 15, 0.002, seed=300 + n_qubits, local=True)
+    tsave = torch.linspace(0, 0.024, 5, dtype=torch.float64)
+    gen = torch.Generator().manual_seed(n_qubits)
+    psi = torch.randn(batch, 2**n_qubits, generator=gen, dtype=torch.complex128)
+    psi = (psi / psi.norm(dim=1, keepdim=True)).to(cuda_device)
+    obs = R.total_magnetization_diag(n_qubits)[None].to(cuda_device)
+    scale = torch.linspace(0.7, 1.3, batch, dtype=torch.float64, device=cuda_device)[:, None, None]
+    out = {}
+    for variant in (2, 10):
+        amp, det, u, spec = to_native(terms, cuda_device, SolverType.KRYLOV_SE, store_states=store, batch_tables=batch)
+        spec.kernel_variant = variant
+        amp = (amp * scale).detach().requires_grad_(True)  # every trajectory its own tables
+        det = (det * scale).detach().requires_grad_(True)
+        u.requires_grad_(True)
+        states, expect = evolve(amp, det, u, tsave, psi, spec, obs)
+        w = torch.linspace(0.5, 1.5, expect.shape[1], dtype=torch.float64, device=cuda_device)
+        (expect[0] * w[:, None]).sum().backward()
+        out[variant] = [states.detach().cpu().numpy(), expect.detach().cpu().numpy(), amp.grad.cpu().numpy(), det.grad.cpu().numpy(),
+                        u.grad.cpu().numpy()]
+    for name, a, b in zip(("states", "expect", "amp", "det", "u"), out[2], out[10]):
+        if a.size:
+            assert rel_err(b, a) < 1e-12, name
 
 
 def test_chained_tile_kernels_against_matrix_free_oracle(cuda_device):
@@ -333,6 +362,18 @@ def test_c_abi_error_codes_map_to_reference_exception_types(cuda_device):
         evolve(amp, det, u, torch.tensor([0.0, 0.01], dtype=torch.float64), psi0, bad, None)
     with pytest.raises(ValueError):
         _native.set_kernel_variant(99)
+    bad_variant = to_native(terms, cuda_device, SolverType.KRYLOV_SE)[3]
+    bad_variant.kernel_variant = 99  # the C library validates the field too (RydProblem.kernel_variant)
+    with pytest.raises(ValueError, match="kernel_variant"):
+        evolve(amp, det, u, torch.tensor([0.0, 0.01], dtype=torch.float64), psi0, bad_variant, None)
+    with pytest.raises(ValueError, match="amp_tables must have shape"):
+        evolve(amp[:, :, :-1], det, u, torch.tensor([0.0, 0.01], dtype=torch.float64), psi0, spec, None)
+    with pytest.raises(ValueError, match="u_pairs must hold"):
+        evolve(amp, det, u[:-1], torch.tensor([0.0, 0.01], dtype=torch.float64), psi0, spec, None)
+    with pytest.raises(ValueError, match="obs_diag must have shape"):
+        evolve(amp, det, u, torch.tensor([0.0, 0.01], dtype=torch.float64), psi0, spec, torch.zeros(1, 4, dtype=torch.float64, device=cuda_device))
+    # a NULL problem is an error code, not a host crash
+    assert _native.lib().rydiff_apply_factor(None, None, None, None, None, None, None, 0, None, None, 0, None, 0, None) == _native.RYDIFF_EINVAL
     # too small a workspace is reported, not overrun
     L = _native.lib()
     from pulser_diff_amd.solver import _Call
@@ -458,3 +499,77 @@ def test_stored_states_keep_the_full_tape_for_the_gradient(cuda_device, n_qubits
         out[mode] = [states.detach().cpu(), expect.detach().cpu()] + [l.grad.detach().cpu() for l in leaves]
     for name, a, b in zip(("states", "expect", "amp", "det", "u", "tsave", "psi0"), out["steps"], out["auto"]):
         assert rel_err(b.numpy(), a.numpy()) < 1e-11, name
+
+
+def test_two_threads_two_streams_two_kernel_variants(cuda_device):
+    """The C ABI keeps no process state (include/rydiff.h, "Threads and streams"): two host threads drive two problems with
+    DIFFERENT kernel variants on two HIP streams at the same time, several rounds each, and both reproduce their single-threaded
+    results to rounding."""
+    import threading
+
+    from pulser_diff_amd.solver import SolverType, evolve
+
+    n = 13
+    terms = random_terms(n, 13, 0.002, seed=913, local=True)
+    tsave = torch.linspace(0, 0.022, 5, dtype=torch.float64)
+    zd = R.total_magnetization_diag(n)[None].to(cuda_device)
+    psi0 = R.all_ground_state(n).T.contiguous().to(cuda_device)
+
+    def run(variant, stream=None):
+        amp, det, u, spec = to_native(terms, cuda_device, SolverType.KRYLOV_SE, store_states=False)
+        spec.kernel_variant = variant  # travels in RydProblem: nothing is set on the library
+        amp.requires_grad_(True)
+        det.requires_grad_(True)
+        ctx = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream(cuda_device))
+        with ctx:
+            _, expect = evolve(amp, det, u, tsave, psi0, spec, zd)
+            (expect[0, -1, 0] + 0.5 * expect[0, 2, 0]).backward()
+            (stream or torch.cuda.current_stream(cuda_device)).synchronize()
+        return [expect.detach().cpu().numpy(), amp.grad.cpu().numpy(), det.grad.cpu().numpy()]
+
+    single = {v: run(v) for v in (1, 2)}
+    for a, b in zip(single[1], single[2]):  # the two kernel families agree with each other to rounding
+        assert rel_err(a, b) < 1e-11
+    results, errors = {}, []
+
+    def worker(variant):
+        try:
+            st = torch.cuda.Stream(device=cuda_device)
+            st.wait_stream(torch.cuda.current_stream(cuda_device))
+            results[variant] = [run(variant, st) for _ in range(4)]
+        except Exception as exc:  # surfaced in the main thread
+            errors.append((variant, exc))
+
+    torch.cuda.synchronize()
+    threads = [threading.Thread(target=worker, args=(v,)) for v in (1, 2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for v in (1, 2):
+        for rnd in results[v]:
+            for a, b in zip(rnd, single[v]):  # (reductions use atomics: the summation order is free, hence not bit-identical)
+                assert rel_err(a, b) < 1e-12
+
+
+def test_negative_pair_interactions_stay_inside_the_design_interval(cuda_device):
+    """Spectral bound with NEGATIVE U_ij (the master-equation path puts -U_ij on the column qubits of its doubled
+    register): the diagonal ranges over [-sum of negative U, +sum of positive U].  A strongly interacting register with mixed
+    signs must match the oracle's dense exponential; with a one-sided bound part of the spectrum sat outside the polynomial's
+    design interval and the map lost orders of accuracy (or diverged)."""
+    from pulser_diff_amd.solver import SolverType, evolve
+
+    n = 6
+    terms = random_terms(n, 21, 0.004, seed=4242, local=True, spacing=5.2)  # U_nn ~ 270 rad/us
+    sign = torch.tensor([1.0 if k % 2 else -1.0 for k in range(len(terms.u_pairs))], dtype=torch.float64)
+    terms.u_pairs = terms.u_pairs * sign
+    tsave = torch.linspace(0, 0.08, 9, dtype=torch.float64)
+    psi0 = torch.randn(2**n, 1, generator=torch.Generator().manual_seed(1), dtype=torch.complex128)
+    psi0 = psi0 / psi0.norm()
+    ref = R.krylov_map_dense(terms, psi0, tsave)
+    amp, det, u, spec = to_native(terms, cuda_device, SolverType.KRYLOV_SE)
+    states, _ = evolve(amp, det, u, tsave, psi0.T.contiguous().to(cuda_device), spec, None)
+    stats = spec.options["_last_stats"]
+    assert stats["spectral"][0] < -float(terms.u_pairs.clamp(max=0).abs().sum()) + 1e-9  # the bound reaches below -sum |U_neg|
+    assert rel_err(states.cpu().permute(0, 2, 1).numpy(), ref.numpy()) < 1e-9

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import restatement as R
-from tests.helpers import random_terms
+from tests.helpers import random_terms, rel_err
 
 
 @pytest.mark.parametrize("n_qubits,local", [(1, False), (2, True), (4, True), (6, False)])
@@ -70,3 +70,50 @@ def test_expect_and_total_magnetization_conventions():
         psi = R.all_ground_state(n)
         val = R.expect(R.total_magnetization(n), psi[None])
         assert abs(val.item().real + n) < 1e-14
+
+
+def test_matrix_free_torch_map_and_its_autograd_match_the_dense_map():
+    """krylov_map_matrix_free_torch (Taylor series, matrix-free, differentiable: the source of the 14- and 20-qubit gradient
+    goldens) against krylov_map_dense (dense matrix exponential, pinned by the notebook values): states and all five gradient
+    kinds, global + local terms with phases, batch of two columns, with and without per-step checkpointing."""
+    n = 5
+    terms = random_terms(n, 15, 0.002, seed=5, local=True)
+    tsave = torch.tensor([0.0, 0.0031, 0.007, 0.012, 0.02], dtype=torch.float64)
+    psi0 = torch.randn(2**n, 2, generator=torch.Generator().manual_seed(0), dtype=torch.complex128)
+    zd = R.total_magnetization_diag(n)
+
+    def run(fn):
+        o = R.HamTerms(n, terms.u_pairs.clone().requires_grad_(True), terms.amp_coeff.clone().requires_grad_(True),
+                       terms.det_coeff.clone().requires_grad_(True), terms.dt, terms.n_samples, terms.amp_targets, terms.det_targets)
+        o.extra_amp = [(c.clone().requires_grad_(True), tg) for c, tg in terms.extra_amp]
+        o.extra_det = [(c.clone().requires_grad_(True), tg) for c, tg in terms.extra_det]
+        ts = tsave.clone().requires_grad_(True)
+        p0 = psi0.clone().requires_grad_(True)
+        st = fn(o, p0, ts)
+        (((st.abs() ** 2) * zd[None, :, None]).sum() * 0.3 + (st[-1].real * torch.arange(2**n)[:, None]).sum()).backward()
+        return st.detach(), [o.u_pairs.grad, o.amp_coeff.grad, o.det_coeff.grad, ts.grad, p0.grad, o.extra_amp[0][0].grad, o.extra_det[0][0].grad]
+
+    ref, gref = run(R.krylov_map_dense)
+    for ckpt in (False, True):
+        got, ggot = run(lambda o, p, t: R.krylov_map_matrix_free_torch(o, p, t, checkpoint=ckpt))
+        assert rel_err(got.numpy(), ref.numpy()) < 1e-13
+        for a, b in zip(ggot, gref):
+            assert rel_err(a.numpy(), b.numpy()) < 1e-11
+
+
+def test_committed_gradient_fixture_is_what_the_generator_produces(tmp_path, monkeypatch):
+    """tests/golden/grad_dense_n8.npz regenerated from scratch by tests/golden/make_baseline_fixtures.py: the committed numbers
+    are the oracle's, not hand-edited (the larger fixtures come from the same code paths)."""
+    import importlib.util
+    from pathlib import Path
+
+    gold = Path(__file__).parent / "golden"
+    spec = importlib.util.spec_from_file_location("make_baseline_fixtures", gold / "make_baseline_fixtures.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(mod, "OUT", tmp_path)
+    mod.MAKERS["grad_dense_n8"]()
+    new, old = np.load(tmp_path / "grad_dense_n8.npz"), np.load(gold / "grad_dense_n8.npz")
+    assert sorted(new.files) == sorted(old.files)
+    for k in old.files:
+        assert rel_err(new[k], old[k]) < 1e-10, k
