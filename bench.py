@@ -381,6 +381,7 @@ def run_trajectories(args, workload: str, rank: int, world: int, device, barrier
             times.append(e0.elapsed_time(e1))
             om.grad = None
             de.grad = None
+            del ex, l, amp_b, det_b  # frees the run's tape workspace before the next run plans its own (two full tapes do not fit)
         bwd_ms = times[-1]
         tape = spec_b.options["_last_stats"].get("tape")
         n_launch = total_factors * (1 if tape == "full" else 2)  # one state per save point: recompute pass + adjoint pass per factor

@@ -1365,17 +1365,17 @@ struct ChainStep {
     long exp_ostride = 0;
 };
 
-template <int LGT, bool CPLX, bool BWD, bool FAST = false>
+template <int LGT, bool CPLX, bool BWD, bool FAST = false, bool RES = false>
 int launch_chain_t(const ChainArgs& ca, unsigned tiles, hipStream_t stream) {
     if constexpr (!FAST) {  // one global drive, at most one detuning group: the loop-free instantiation
         if (ca.ga == 1 && ca.gd <= 1 && ca.sta_mask[0] == (1u << kTileBits) - 1u)
-            return launch_chain_t<LGT, CPLX, BWD, true>(ca, tiles, stream);
+            return launch_chain_t<LGT, CPLX, BWD, true, RES>(ca, tiles, stream);
     }
     // tile + reduction scratch: one double per wave (forward), [4 ga + gd] slots per wave (adjoint: parked gradient partials)
     const size_t nw = (size_t(1) << LGT) / 64;
     const size_t max_lds = (size_t(1) << kTileBits) * sizeof(double2) + 256 + (BWD ? size_t(5) * kMaxGroups * nw * sizeof(double) : 0);
     const size_t lds = (size_t(1) << kTileBits) * sizeof(double2) + 256 + (BWD ? size_t(4 * ca.ga + ca.gd) * nw * sizeof(double) : 0);
-    auto kern = k_chain<kTileBits, LGT, CPLX, BWD, FAST>;
+    auto kern = k_chain<kTileBits, LGT, CPLX, BWD, FAST, RES>;
     // once per instantiation and process; idempotent, so a race between two first callers is harmless
     static std::atomic<bool> attr_set{false};
     if (!attr_set.load(std::memory_order_acquire)) {
@@ -1388,12 +1388,12 @@ int launch_chain_t(const ChainArgs& ca, unsigned tiles, hipStream_t stream) {
     return RYDIFF_OK;
 }
 
-template <int LGT>
+template <int LGT, bool RES = false>
 int launch_chain_l(const ChainArgs& ca, unsigned tiles, bool cplx, bool bwd, hipStream_t stream) {
     // the adjoint needs both partner sums (plain and signed) unless the coefficients are real AND the caller only uses the
     // real part of the amplitude gradients (RydProblem.real_amp_grad): then `cplx` arrives false here
-    if (bwd) return cplx ? launch_chain_t<LGT, true, true>(ca, tiles, stream) : launch_chain_t<LGT, false, true>(ca, tiles, stream);
-    return cplx ? launch_chain_t<LGT, true, false>(ca, tiles, stream) : launch_chain_t<LGT, false, false>(ca, tiles, stream);
+    if (bwd) return cplx ? launch_chain_t<LGT, true, true, false, RES>(ca, tiles, stream) : launch_chain_t<LGT, false, true, false, RES>(ca, tiles, stream);
+    return cplx ? launch_chain_t<LGT, true, false, false, RES>(ca, tiles, stream) : launch_chain_t<LGT, false, false, false, RES>(ca, tiles, stream);
 }
 
 // cotangents handed to the backward call (fused injection, see ChainArgs / FactorBwdArgs)
@@ -1489,6 +1489,8 @@ int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, const BatchSl
     // auto: 1024 threads per tile for the forward passes, 512 for the (register-hungrier) adjoint passes
     // (the real-drive adjoint, without the signed sums, fits 1024 threads too: measured 2710 -> 2767 steps/s on C3)
     const int lgt = rt.variant == 0 ? ((cs.bwd && cplx) ? 9 : 10) : rt.chain_lgt;
+    if (bs.xcd)  // L2-resident placement (automatic thread counts only: variant 10 decodes to 0)
+        return lgt == 9 ? launch_chain_l<9, true>(ca, tiles, cplx, cs.bwd, stream) : launch_chain_l<10, true>(ca, tiles, cplx, cs.bwd, stream);
     switch (lgt) {
         case 8: return launch_chain_l<8>(ca, tiles, cplx, cs.bwd, stream);
         case 10: return launch_chain_l<10>(ca, tiles, cplx, cs.bwd, stream);
@@ -1796,19 +1798,18 @@ namespace {
 // stores, so that the complete vector + partial of m trajectories (m * 32 * 2^N bytes) stay in each XCD's 4 MiB L2 from pass to
 // pass and only the write-back crosses the fabric.  Every group runs its WHOLE sweep before the next one starts.  Returns the
 // group size (0: off).  Placement changes speed only: results are the same as with the plain grid (A/B-tested).
-int xcd_group_size(const Runtime& rt) {
+int xcd_group_size(const Runtime& rt, bool adjoint) {
     const Plan& pl = rt.pl;
     if (!chain_enabled(rt) || chain_layout_count(pl.N, rt.force_three) != 2) return 0;
     const size_t live = size_t(32) << pl.N;    // complete vector + partial of one trajectory
     const size_t budget = size_t(3) << 20;     // of the 4 MiB L2 (the rest: tape lines on their way out, tables)
-    if (!rt.force_xcd) {
-#ifdef RYDIFF_AUTO_XCD
-        if (rt.variant != 0 || pl.B < 8 || live > budget) return 0;
-#else
-        return 0;
-#endif
-    }
     const int m = int(std::max<size_t>(1, budget / live));
+    if (rt.force_xcd) return 8 * m;
+    // Measured (profiles/r02_xcd_placement.txt): a launch of <= 256 tiles is bound by the ~10 us one tile keeps its CU busy, not by
+    // the fabric, so SEVERAL groups in sequence lose to one launch over the whole batch (16 qubits x 32: 38 vs 27 us per pass).
+    // Where ONE group covers the batch the forward passes gain (16 qubits x 8: 14.2 -> 9.8 us; 13 qubits x 64: 12.1 -> 9.6 us);
+    // the adjoint passes, which stream two tape vectors anyway, do not (17.1 vs 17.3 us).
+    if (rt.variant != 0 || adjoint || pl.B < 8 || pl.B > 8 * m || live > budget) return 0;
     return 8 * m;
 }
 
@@ -1946,7 +1947,7 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
             }
         }
         const bool full_tape = full_ws_tape;
-        const int grp = xcd_group_size(rt);
+        const int grp = xcd_group_size(rt, false);
         for (int b0 = 0; b0 < pl.B; b0 += (grp ? grp : pl.B)) {
             const BatchSlice bs{b0, std::min(grp ? grp : pl.B, pl.B - b0), grp > 0};
             int flip = 0;
@@ -2114,7 +2115,7 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
     }
 
     const bool chained = chain_enabled(rt);
-    const int grp = (!persisted && chained) ? xcd_group_size(rt) : 0;
+    const int grp = (!persisted && chained) ? xcd_group_size(rt, true) : 0;
     const int cl0 = cl;
     auto sweep = [&](const BatchSlice& bs) -> int {
         std::vector<ChainItem> chain, part;
