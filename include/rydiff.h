@@ -119,6 +119,34 @@ typedef struct RydProblem {
      * "automatic" takes the one-launch sweeps up to 12 qubits, the direct kernels while few tiles are in flight
      * (B * 2^N <= 2^18) and the chained passes beyond.  Results do not depend on the variant beyond rounding. */
     int32_t kernel_variant;
+
+    /* STATE-SHARDED forward runs (BASELINE config 5; the reference has no counterpart: it keeps the whole
+     * state in one process).  shard_bits = g > 0: the top g qubits (qubits 0..g-1 = the top g bits of the amplitude index)
+     * select the RANK; every rank owns a contiguous slab of 2^(N-g) amplitudes.  n_qubits, the masks and u_pairs describe the
+     * WHOLE register; `batch` = number of ranks whose slabs are part of THIS call, rank ids shard_rank_first ... + batch - 1,
+     * and psi0 / states_out / obs_diag are laid out per slab: [batch][2^(N-g)] (obs_diag: [n_obs][batch][2^(N-g)]).
+     * expect_out [n_obs][n_tsave][batch] receives every slab's PARTIAL sum (the caller adds them / all-reduces them).
+     * One factor pass = the local pass on the N-g slab qubits (same kernels, diagonal evaluated at the global index) plus
+     * beta * (c or conj c) * the partner rank's slab for each of the g rank qubits (partner of rank bit k: rank ^ (1 << k)):
+     *   - batch == 2^g (every rank in this call, e.g. all of them on one device): partners are read in place;
+     *   - otherwise shard_recv[k] (HOST array of g DEVICE buffers of 2^(N-g) amplitudes) must hold the partner's current slab
+     *     whenever a pass needs it, and shard_exchange says when: it is called (on the calling thread) with phase 0 right
+     *     after the launch that produced the slab `src` (nbytes) which the partners need next — post the sends of `src` and
+     *     the receives into shard_recv[] there, ordered after the work enqueued on `stream` so far — and with phase 1 before
+     *     the first launch that reads shard_recv[] — make `stream` wait for those receives there.  The library runs the whole
+     *     trajectory (every step, every factor) in ONE call and never touches the transport itself (torch.distributed /
+     *     RCCL stay with the caller).  A non-zero return aborts the run with RYDIFF_EHIP.
+     * Forward only (need_tape = 0, no rydiff_backward), no pair terms, 1 <= N-g, N <= RYDIFF_MAX_QUBITS. */
+    int32_t shard_bits;
+    int32_t shard_rank_first;
+    void* const* shard_recv;
+    int (*shard_exchange)(void* user, int phase, const void* src, size_t nbytes);
+    void* shard_user;
+
+    /* rydiff_forward: != 0: states_out is [1][B][2^N] and receives only the state at the LAST evaluation time (a 24-qubit
+     * trajectory would otherwise need n_tsave x 256 MiB).  Launch-per-factor kernels only (more than 12 qubits, or a
+     * state-sharded run); not together with need_tape. */
+    int32_t final_state_only;
 } RydProblem;
 
 /* Result of rydiff_plan(): everything that depends on the VALUES in the coefficient tables. */

@@ -54,7 +54,17 @@ class RydProblem(ctypes.Structure):
         ("pair_tables", ctypes.c_void_p),
         ("real_amp_grad", ctypes.c_int32),
         ("kernel_variant", ctypes.c_int32),
+        ("shard_bits", ctypes.c_int32),
+        ("shard_rank_first", ctypes.c_int32),
+        ("shard_recv", ctypes.c_void_p),
+        ("shard_exchange", ctypes.c_void_p),
+        ("shard_user", ctypes.c_void_p),
+        ("final_state_only", ctypes.c_int32),
     ]
+
+
+# int (*shard_exchange)(void* user, int phase, const void* src, size_t nbytes)  (include/rydiff.h, state-sharded runs)
+SHARD_EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t)
 
 
 class RydPlanInfo(ctypes.Structure):

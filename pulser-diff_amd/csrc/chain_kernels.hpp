@@ -90,6 +90,18 @@ struct ChainArgs {
     const double* inj_obs;      // [n_obs][dim]
     int inj_n_obs;
     long inj_ostride;           // n_tsave * B
+    // STATE-SHARDED run (forward passes only): the vectors are SLABS of 2^nl amplitudes,
+    // trajectory b of the launch is the slab of rank sh_rank_first + b (the rank id = the top sh_bits bits of the global
+    // amplitude index).  The tile geometry is that of the nl local qubits; the diagonal is evaluated at the GLOBAL index; the
+    // flips of the sh_bits "rank qubits" are the partner ranks' slabs, added — times beta * (c or conj c) — by the launch
+    // that completes a factor.
+    int sh_bits;                       // 0: not sharded
+    int sh_nl;
+    int sh_rank_first;
+    int sh_self;                       // 1: every rank lives on this device, partner of trajectory b for rank bit k is trajectory b ^ (1 << k) of `u`
+    const double2* sh_rem[kShardMaxBits];  // sh_self = 0: slab received from the partner of rank bit k (holds ITS complete v_{j-1}), trajectory 0
+    int sh_grp[kShardMaxBits];         // flip group (coefficient record slot) of the qubit behind rank bit k, -1: not driven
+    long obs_bstride, obs_ostride;     // observable table: [n_obs][dim] (0, dim), sharded: one slab per rank [n_obs][ranks][2^nl] (dim, ranks * dim)
     // fused expectation values of the COMPLETE vector produced by the finish stage (forward mode, step ends)
     const double* obs;      // [n_obs][dim] or nullptr
     double* expect_slot;    // &expect_out[0][k][0]
@@ -290,6 +302,9 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     if (bl >= unsigned(a.b_count)) return;                                                 // ragged last row of 8
     const unsigned bt = unsigned(a.b_first) + bl;                                          // trajectory
     const size_t boff = size_t(bt) * a.dim;
+    const unsigned rank = unsigned(a.sh_rank_first) + bl;                 // sharded runs: this slab's rank id ...
+    const unsigned rank_hi = a.sh_bits ? (rank << a.sh_nl) : 0u;           // ... = the top bits of the global amplitude index
+    const unsigned t_glob = a.sh_bits ? (t + (rank << (a.sh_nl - LT))) : t;  // row of the (global) split-diagonal table
     auto ld = [&](const double2* p) -> double2 {
         if constexpr (RES) return *p;
         else return stream_load(p);
@@ -318,6 +333,26 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     if (a.has_p) {
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = ld(a.p + boff + xg[r]);
+    }
+    // sharded runs: flips of the rank qubits = the partner slabs' complete v_{j-1} at the same local index, times
+    // beta * (c or conj c).  Requested together with u and p so that all of a tile's global loads are in flight at once.
+    double2 remacc[R];
+    if (!BWD && a.has_p && a.sh_bits) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) remacc[r] = make_double2(0.0, 0.0);
+        const double* __restrict__ cfs = a.coef_fin + bt * a.coef_bstride;
+        for (int k = 0; k < a.sh_bits; ++k) {
+            if (a.sh_grp[k] < 0) continue;
+            const double cr = cfs[a.sh_grp[k]], ci = (rank >> k & 1u) ? cfs[a.ga + a.sh_grp[k]] : -cfs[a.ga + a.sh_grp[k]];  // row g: c, row r: conj c
+            const double kr = a.fb_r * cr - a.fb_i * ci, ki = a.fb_r * ci + a.fb_i * cr;
+            const double2* __restrict__ src = a.sh_self ? a.u + size_t(unsigned(a.b_first) + (bl ^ (1u << k))) * a.dim : a.sh_rem[k] + size_t(bl) * a.dim;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double2 pv = stream_load(src + xg[r]);
+                remacc[r].x += kr * pv.x - ki * pv.y;
+                remacc[r].y += kr * pv.y + ki * pv.x;
+            }
+        }
     }
     double dg[R];  // tile-local part of the interaction diagonal (32 KiB table shared by all tiles: L2-resident)
     if (a.has_q) {
@@ -398,6 +433,13 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = uu[r];
     }
+    if (!BWD && a.has_p && a.sh_bits) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            acc[r].x += remacc[r].x;
+            acc[r].y += remacc[r].y;
+        }
+    }
     if (BWD && a.has_p && (a.inj_gexp || a.inj_gstate)) {  // wave-uniform: the completed cotangent sits at a save point
         if (a.inj_gexp) {
             bool any = false;
@@ -435,7 +477,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
         for (int o = 0; o < a.n_obs; ++o) {
             double e = 0.0;
 #pragma unroll
-            for (int r = 0; r < R; ++r) e += a.obs[size_t(o) * a.dim + xg[r]] * (acc[r].x * acc[r].x + acc[r].y * acc[r].y);
+            for (int r = 0; r < R; ++r) e += a.obs[size_t(o) * a.obs_ostride + bt * a.obs_bstride + xg[r]] * (acc[r].x * acc[r].x + acc[r].y * acc[r].y);
             wg_atomic_add<NT>(e, a.expect_slot + o * a.exp_ostride + bt, red);
         }
     }
@@ -455,7 +497,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     const double* __restrict__ cf = a.coef_sta + bt * a.coef_bstride;
     // interaction diagonal: remote part of this tile + cross terms of the tile bits that are in |r> (n = 1 - bit)
     double vloc[LT];
-    const double* __restrict__ vrow = a.vr + size_t(t) * 16;
+    const double* __restrict__ vrow = a.vr + size_t(t_glob) * 16;
 #ifdef RYDIFF_ABLATE_COEF
     for (int b2 = 0; b2 < LT; ++b2) vloc[b2] = a.sb_r;
     double dlane = a.sb_i;
@@ -479,7 +521,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
         for (int g = 0; g < GD; ++g) {
             double sgd = 0.0;
 #pragma unroll
-            for (int r = 0; r < R; ++r) sgd += rr[r] * double(a.dcnt[g] - __popc(xg[r] & a.dmask[g]));
+            for (int r = 0; r < R; ++r) sgd += rr[r] * double(a.dcnt[g] - __popc((xg[r] | rank_hi) & a.dmask[g]));
             park1<NW>(sgd, red, 2 * a.ga + g);
         }
     }
@@ -491,9 +533,9 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
         for (int b2 = LGT; b2 < LT; ++b2)
             if (!(r >> (b2 - LGT) & 1)) d += vloc[b2];
         if (FAST) {
-            if (GD) d += cf[2] * double(a.dcnt[0] - __popc(xg[r] & a.dmask[0]));
+            if (GD) d += cf[2] * double(a.dcnt[0] - __popc((xg[r] | rank_hi) & a.dmask[0]));
         } else {
-            for (int g = 0; g < a.gd; ++g) d += cf[2 * a.ga + g] * double(a.dcnt[g] - __popc(xg[r] & a.dmask[g]));
+            for (int g = 0; g < a.gd; ++g) d += cf[2 * a.ga + g] * double(a.dcnt[g] - __popc((xg[r] | rank_hi) & a.dmask[g]));
         }
         const double dr = a.sg_r + a.sb_r * d, di = a.sg_i + a.sb_i * d;
         q[r].x = dr * acc[r].x - di * acc[r].y;

@@ -43,8 +43,11 @@ struct Groups {
 };
 
 struct Plan {
-    int N = 0;
-    size_t dim = 0;
+    int N = 0;       // qubits of the whole register
+    int NL = 0;      // qubits that index a vector of this call: N, or N - shard_bits for a state-sharded run (slabs)
+    int shard_bits = 0, rank_first = 0;
+    bool shard_self = false;  // every rank's slab is part of this call (partners are read in place)
+    size_t dim = 0;  // 2^NL
     int B = 1, Bc = 1, T = 0, n_samples = 0, Ka = 0, Kd = 0, n_obs = 0, solver = 0;
     double dt = 0.0, tol = 1e-13, ode_tol = 1e-9;
     Groups ga, gd;
@@ -184,7 +187,30 @@ inline bool build_plan(const RydProblem* p, Plan& pl, std::string& err, double w
         pl.pair_radius += worst;
     }
     pl.N = p->n_qubits;
-    pl.dim = size_t(1) << pl.N;
+    pl.shard_bits = p->shard_bits;
+    if (pl.shard_bits < 0 || pl.shard_bits > 6 || pl.shard_bits >= pl.N) {
+        err = "shard_bits must be in [0, min(6, n_qubits - 1)]";
+        return false;
+    }
+    pl.NL = pl.N - pl.shard_bits;
+    pl.rank_first = p->shard_rank_first;
+    if (pl.shard_bits) {
+        const int world = 1 << pl.shard_bits;
+        if (p->coeff_batch != 1 || p->n_pair_terms != 0) {
+            err = "state-sharded runs take shared coefficient tables (coeff_batch = 1) and no pair terms";
+            return false;
+        }
+        if (pl.rank_first < 0 || pl.rank_first + p->batch > world) {
+            err = "shard_rank_first + batch exceeds 2^shard_bits";
+            return false;
+        }
+        pl.shard_self = p->batch == world;
+        if (!pl.shard_self && (!p->shard_recv || !p->shard_exchange || p->batch != 1)) {
+            err = "state-sharded run with ranks elsewhere: one slab per call (batch = 1), shard_recv and shard_exchange required";
+            return false;
+        }
+    }
+    pl.dim = size_t(1) << pl.NL;
     pl.B = p->batch;
     pl.Bc = p->coeff_batch;
     pl.T = p->n_tsave - 1;
@@ -315,7 +341,7 @@ inline bool build_plan(const RydProblem* p, Plan& pl, std::string& err, double w
 // needs total_factors+1 states of HBM — e.g. 156 GiB for N=20, T=1000, which an MI355X's 288 GB holds)
 inline size_t carve(Plan& pl, int tape_mode, bool need_backward, int chain_slots, int64_t total_factors = 0) {
     // factor table of the persistent small-N kernel: 40 bytes per factor pass
-    pl.ptable_bytes = pl.N <= 12 ? size_t(total_factors) * 48 + 64 : 0;  // sizeof(PersistFactor)
+    pl.ptable_bytes = (pl.N <= 12 && !pl.shard_bits) ? size_t(total_factors) * 48 + 64 : 0;  // sizeof(PersistFactor)
     const size_t E = pl.stages.size();
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -327,13 +353,16 @@ inline size_t carve(Plan& pl, int tape_mode, bool need_backward, int chain_slots
     pl.off_meta_idx = take(E * 24);  // StageDev records (rydiff.hip)
     pl.off_members = take(2 * kMaxGroups * sizeof(uint64_t));
     pl.off_coef = take(size_t(pl.Bc) * E * std::max(pl.NC, 1) * sizeof(double));
-    pl.off_udiag = take(pl.dim * sizeof(double));
+    pl.off_udiag = take(pl.dim * sizeof(double) * (pl.shard_bits ? size_t(pl.B) : 1));  // sharded: one table per slab
     pl.off_buf0 = take(pl.state_bytes);
     pl.off_buf1 = take(pl.state_bytes);
     pl.off_pp0 = take(pl.state_bytes);  // partial vectors of the chained passes
     pl.off_pp1 = take(pl.state_bytes);
     // split interaction diagonal for the two tile layouts: utt[2][4096] + vr[2][tiles][16]
-    pl.off_split = take(3 * (4096 + (pl.dim >> 11 ? (pl.dim >> 11) : 1) * 16) * sizeof(double));  // up to three tile layouts
+    {   // (sharded runs index the table by the GLOBAL tile: 2^(N-12) rows)
+        const size_t gdim = size_t(1) << pl.N;
+        pl.off_split = take(3 * (4096 + (gdim >> 11 ? (gdim >> 11) : 1) * 16) * sizeof(double));  // up to three tile layouts
+    }
     pl.off_ptable = take(pl.ptable_bytes);
     if (pl.ptable_bytes) {
         pl.off_pm_begin = take(size_t(pl.T + 1) * sizeof(int32_t));

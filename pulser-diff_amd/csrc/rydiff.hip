@@ -37,6 +37,7 @@ using namespace rydiff;
 // gradient accumulators are replicated so that concurrent blocks do not serialise on one address
 constexpr int kGradReplicas = 64;
 constexpr int kMaxRemote = 6;  // up to 2^6 GPUs in a state-sharded run
+constexpr int kShardMaxBits = 6;  // natively driven sharded runs: up to 2^6 ranks
 
 static thread_local std::string g_last_error;  // the only mutable per-thread state (include/rydiff.h: rydiff_last_error)
 #ifndef RYDIFF_TILE_BITS
@@ -117,6 +118,10 @@ struct FactorArgs {
     const double2* remote[kMaxRemote];
     double rc[2 * kMaxRemote];
     PairArgs pair;
+    // state-sharded run driven natively (ChainArgs documents the fields): slabs as trajectories, rank qubits as partner slabs
+    int sh_bits = 0, sh_nl = 0, sh_rank_first = 0, sh_self = 0;
+    const double2* sh_rem[kShardMaxBits] = {};
+    int sh_grp[kShardMaxBits] = {};
     // fused <y|O|y> of the vector this launch produces (k_factor_direct_global only; last factor of a time step)
     const double* obs = nullptr;   // [n_obs][dim]
     double* expect_slot = nullptr; // &expect_out[0][k][0]
@@ -195,9 +200,13 @@ __device__ __forceinline__ void block_atomic_add(double v, double* dst, double* 
 // ------------------------------------------------------------------------------------------------
 // K6: static interaction diagonal  U(x) = sum_{i<j} U_ij n_i(x) n_j(x),  n_j = 1 - bit_{N-1-j}(x)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_build_udiag(double* __restrict__ udiag, const double* __restrict__ u_pairs, int N, uint32_t dim) {
-    uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= dim) return;
+// sharded runs: one table per slab (blockIdx.y), evaluated at the global index x | (rank << nl)
+__global__ void k_build_udiag(double* __restrict__ udiag, const double* __restrict__ u_pairs, int N, uint32_t dim, int nl = 0,
+                              int rank_first = 0) {
+    const uint32_t xl = blockIdx.x * blockDim.x + threadIdx.x;
+    if (xl >= dim) return;
+    udiag += size_t(blockIdx.y) * dim;
+    const uint32_t x = xl | (nl ? ((uint32_t(rank_first) + blockIdx.y) << nl) : 0u);
     double s = 0.0;
     int k = 0;
     for (int i = 0; i < N; ++i) {
@@ -207,7 +216,7 @@ __global__ void k_build_udiag(double* __restrict__ udiag, const double* __restri
             if (ni && nj) s += u_pairs[k];
         }
     }
-    udiag[x] = s;
+    udiag[xl] = s;
 }
 
 // split form of the interaction diagonal for one tile layout (chain_kernels.hpp):
@@ -397,10 +406,14 @@ __global__ void k_expand_coeffs(ExpandArgs a) {
 //   d(x) = U(x) + sum_g dcoef_g * (#qubits of g in |r>)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double diag_value(const double* __restrict__ udiag, const double* __restrict__ cf, const GroupArgs& g,
-                                             uint32_t x) {
+                                             uint32_t x, uint32_t xglob) {
     double d = udiag[x];
-    for (int q = 0; q < g.gd; ++q) d += cf[2 * g.ga + q] * double(g.dcnt[q] - __popc(x & g.dmask[q]));
+    for (int q = 0; q < g.gd; ++q) d += cf[2 * g.ga + q] * double(g.dcnt[q] - __popc(xglob & g.dmask[q]));
     return d;
+}
+__device__ __forceinline__ double diag_value(const double* __restrict__ udiag, const double* __restrict__ cf, const GroupArgs& g,
+                                             uint32_t x) {
+    return diag_value(udiag, cf, g, x, x);
 }
 
 __global__ __launch_bounds__(256) void k_factor_direct(FactorArgs a) {
@@ -409,10 +422,20 @@ __global__ __launch_bounds__(256) void k_factor_direct(FactorArgs a) {
     const size_t boff = size_t(blockIdx.y) * a.dim;
     const double2* __restrict__ xin = a.xin + boff;
     const double* __restrict__ cf = a.use_inline ? a.coef_inline : a.coef + blockIdx.y * a.coef_bstride;
-    const double d = diag_value(a.udiag, cf, a.g, x);
+    const unsigned rank = unsigned(a.sh_rank_first) + blockIdx.y;
+    const uint32_t xglob = a.sh_bits ? (x | (rank << a.sh_nl)) : x;  // sharded: the diagonal lives at the global index
+    const double d = diag_value(a.udiag + (a.sh_bits ? boff : 0), cf, a.g, x, xglob);
     const double2 v = xin[x];
     const double dr = a.gr + a.br * d, di = a.gi + a.bi * d;
     double ar = dr * v.x - di * v.y, ai = dr * v.y + di * v.x;
+    for (int k = 0; k < a.sh_bits; ++k) {  // flips of the rank qubits: partner slabs
+        if (a.sh_grp[k] < 0) continue;
+        const double cr = cf[a.sh_grp[k]], ci = (rank >> k & 1u) ? cf[a.g.ga + a.sh_grp[k]] : -cf[a.g.ga + a.sh_grp[k]];
+        const double kr = a.br * cr - a.bi * ci, ki = a.br * ci + a.bi * cr;
+        const double2 rv = a.sh_self ? a.xin[size_t(blockIdx.y ^ (1u << k)) * a.dim + x] : a.sh_rem[k][boff + x];
+        ar += kr * rv.x - ki * rv.y;
+        ai += kr * rv.y + ki * rv.x;
+    }
     for (int k = 0; k < a.n_remote; ++k) {
         const double2 rv = a.remote[k][boff + x];
         ar += a.rc[2 * k] * rv.x - a.rc[2 * k + 1] * rv.y;
@@ -694,17 +717,19 @@ __global__ __launch_bounds__(256) void k_dot_hx(DotHArgs a) {
 // ------------------------------------------------------------------------------------------------
 // K2: expectation values of diagonal observables, one launch per saved state.
 // ------------------------------------------------------------------------------------------------
+// obs_bstride / obs_ostride: 0 / dim for one observable table shared by the batch; sharded runs: dim / B*dim (one slab per rank)
 __global__ __launch_bounds__(256) void k_expect_diag(const double2* __restrict__ psi, const double* __restrict__ obs,
                                                      double* __restrict__ out /* [n_obs][n_tsave][B] */, int n_obs,
-                                                     int n_tsave, int k, int B, uint32_t dim) {
+                                                     int n_tsave, int k, int B, uint32_t dim, long obs_bstride = 0) {
     __shared__ double lds[8];
     const int b = blockIdx.y;
     const double2* __restrict__ p = psi + size_t(b) * dim;
+    const size_t ostride = obs_bstride ? size_t(B) * dim : dim;
     for (int o = 0; o < n_obs; ++o) {
         double s = 0.0;
         for (uint32_t x = blockIdx.x * 256u + threadIdx.x; x < dim; x += gridDim.x * 256u) {
             const double2 v = p[x];
-            s += obs[size_t(o) * dim + x] * (v.x * v.x + v.y * v.y);
+            s += obs[size_t(o) * ostride + size_t(b) * obs_bstride + x] * (v.x * v.x + v.y * v.y);
         }
         block_atomic_add(s, out + (size_t(o) * n_tsave + k) * B + b, lds);
     }
@@ -954,6 +979,10 @@ struct Runtime {
     bool force_three = false;     // variant 7: three tile layouts wherever they are legal
     bool force_xcd = false;       // variant 10: trajectory-per-XCD placement of the chained tiles forced
     int chain_lgt = 9;            // log2(threads per tile workgroup) of explicitly chosen chained variants
+    // state-sharded run: where the partner slabs arrive and who moves them (RydProblem.shard_recv / shard_exchange)
+    void* const* shard_recv = nullptr;
+    int (*shard_exchange)(void*, int, const void*, size_t) = nullptr;
+    void* shard_user = nullptr;
     GroupArgs garg{};
     PairArgs parg{};
 };
@@ -970,6 +999,9 @@ int decode_variant(const RydProblem* p, Runtime& rt) {
     if (v == 10) v = 0;
     rt.variant = v;
     rt.chain_lgt = v == 3 ? 8 : (v == 4 ? 10 : 9);
+    rt.shard_recv = p->shard_recv;
+    rt.shard_exchange = p->shard_exchange;
+    rt.shard_user = p->shard_user;
     return RYDIFF_OK;
 }
 
@@ -1115,7 +1147,7 @@ void fill_info(const Runtime& rt, double lo, double hi, size_t ws, RydPlanInfo* 
 // 83 vs 78 ms).  Explicit kernel variants are left alone (A/B tests).
 bool few_tiles(const Runtime& rt, bool with_gradients) {
     const Plan& pl = rt.pl;
-    if (rt.variant != 0 || rt.force_three || rt.force_xcd) return false;
+    if (rt.variant != 0 || rt.force_three || rt.force_xcd || pl.shard_bits) return false;
     (void)with_gradients;  // with the unrolled global-drive direct kernels the crossover is 2^18 amplitudes either way
     return (size_t(pl.B) << pl.N) <= (size_t(1) << 18);
 }
@@ -1123,7 +1155,7 @@ bool few_tiles(const Runtime& rt, bool with_gradients) {
 // The full per-factor tape (the adjoint sweep recomputes nothing) goes with the launch-per-factor ADJOINT kernels, chained or
 // direct (12 qubits: the one-launch forward sweep writes it); up to 11 qubits the adjoint sweep is one launch too and keeps
 // one state per tsave.
-bool full_tape_possible(const Plan& pl) { return pl.N > kPersistBwdMaxQubits && pl.n_pair == 0; }
+bool full_tape_possible(const Plan& pl) { return pl.N > kPersistBwdMaxQubits && pl.n_pair == 0 && !pl.shard_bits; }
 
 // common prologue of forward / backward: plan, (optional) stats, carve, upload metadata, expand coefficients, udiag.
 // With `info` given nothing in here waits for the device.
@@ -1151,6 +1183,9 @@ int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_
     rc = finish_runtime(rt, lo, hi);
     if (rc) return rc;
     Plan& pl = rt.pl;
+    if (pl.shard_bits && (need_tape || need_backward))
+        return fail(RYDIFF_ENOTIMPL, "state-sharded runs are forward only here (gradients: pulser-diff_amd/sharded.py grad_distributed)");
+    if (pl.shard_bits) rt.generic_direct = true;  // (the unrolled direct kernels know nothing about rank qubits)
     if (need_tape == 2 && !full_tape_possible(pl)) need_tape = 1;  // full tape only with chained passes
     rt.prefer_direct = few_tiles(rt, need_backward || need_tape != 0);
     const size_t need = carve(pl, need_tape, need_backward, std::max(rt.max_step_factors - 1, 1), rt.total_factors);
@@ -1190,17 +1225,22 @@ int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_
     }
     double* udiag = reinterpret_cast<double*>(ws + pl.off_udiag);
     if (pl.N > 1) {
-        hipLaunchKernelGGL(k_build_udiag, dim3((pl.dim + 255) / 256), dim3(256), 0, stream, udiag, p->u_pairs, pl.N, uint32_t(pl.dim));
+        if (pl.shard_bits)  // one table per slab, evaluated at the global index
+            hipLaunchKernelGGL(k_build_udiag, dim3((pl.dim + 255) / 256, pl.B), dim3(256), 0, stream, udiag, p->u_pairs, pl.N, uint32_t(pl.dim),
+                               pl.NL, pl.rank_first);
+        else
+            hipLaunchKernelGGL(k_build_udiag, dim3((pl.dim + 255) / 256), dim3(256), 0, stream, udiag, p->u_pairs, pl.N, uint32_t(pl.dim));
         LAUNCH_CHECK();
     } else {
         HIP_TRY(hipMemsetAsync(udiag, 0, pl.dim * sizeof(double), stream));
     }
-    if (pl.N > kTileBits && pl.N <= 28) {  // split diagonal for the tile layouts of the chained passes
-        const unsigned tiles = unsigned(pl.dim >> kTileBits);
+    if (pl.NL > kTileBits && pl.NL <= 28) {  // split diagonal for the tile layouts of the chained passes
+        // (sharded runs: the layouts of the NL slab qubits, rows for every tile of the WHOLE register — rank bits on top)
+        const unsigned tiles = unsigned((size_t(1) << pl.N) >> kTileBits);
         double* split = reinterpret_cast<double*>(ws + pl.off_split);
         const size_t per_layout = kTileAmps + size_t(tiles) * 16;
-        for (int l = 0; l < chain_layout_count(pl.N, rt.force_three); ++l) {
-            const LayoutDesc d = chain_layout(pl.N, l, rt.force_three);
+        for (int l = 0; l < chain_layout_count(pl.NL, rt.force_three); ++l) {
+            const LayoutDesc d = chain_layout(pl.NL, l, rt.force_three);
             double* utt = split + l * per_layout;
             hipLaunchKernelGGL(k_build_split, dim3((kTileAmps + tiles + 255) / 256), dim3(256), 0, stream, utt, utt + kTileAmps,
                                p->u_pairs, pl.N, d.lo, d.hs, d.hb, tiles);
@@ -1213,6 +1253,15 @@ int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_
 struct FactorScalars {
     double gr, gi, br, bi;
 };
+
+// state-sharded run with partner ranks elsewhere: tell the caller which slab the partners need next (phase 0, right after the
+// launch that produced it) and when the received slabs are about to be read (phase 1); see RydProblem.shard_exchange
+int shard_signal(const Runtime& rt, int phase, const void* src) {
+    if (!rt.pl.shard_bits || rt.pl.shard_self) return RYDIFF_OK;
+    if (rt.shard_exchange(rt.shard_user, phase, src, rt.pl.dim * sizeof(double2)) != 0)
+        return fail(RYDIFF_EHIP, phase == 0 ? "shard_exchange failed to post the slab exchange" : "shard_exchange failed to wait for the partner slabs");
+    return RYDIFF_OK;
+}
 
 // scalars of factor f of one sub-exponential of duration tau_sub
 FactorScalars factor_scalars(const Runtime& rt, double tau_sub, int f) {
@@ -1250,8 +1299,18 @@ void build_step_chain(const Runtime& rt, int k, std::vector<ChainItem>& chain) {
 // one global drive on a 12..20-qubit register without pair terms: the unrolled direct kernels (k_factor_direct_global)
 bool direct_global_ok(const Runtime& rt) {
     const Plan& pl = rt.pl;
-    return !rt.generic_direct && pl.N >= 12 && pl.N <= 20 && pl.n_pair == 0 && pl.ga.n == 1 &&
+    return !rt.generic_direct && !pl.shard_bits && pl.N >= 12 && pl.N <= 20 && pl.n_pair == 0 && pl.ga.n == 1 &&
            pl.ga.amp_index_mask[0] == (1u << pl.N) - 1u;
+}
+
+// state-sharded runs: flip group behind every rank bit (index bit NL + k), -1 if that qubit is not driven
+void shard_groups(const Plan& pl, int (&grp)[kShardMaxBits]) {
+    for (int k = 0; k < kShardMaxBits; ++k) {
+        grp[k] = -1;
+        if (k >= pl.shard_bits) continue;
+        for (int g = 0; g < pl.ga.n; ++g)
+            if (pl.ga.amp_index_mask[g] >> (pl.NL + k) & 1u) grp[k] = g;
+    }
 }
 
 // obs / expect_slot: fuse <y|O|y> into this launch where the kernel can (returns *fused = true then)
@@ -1272,6 +1331,15 @@ int launch_factor(const Runtime& rt, char* ws, const double2* xin, double2* xout
     fa.bi = s.bi;
     fa.g = rt.garg;
     fa.pair = rt.parg;
+    if (pl.shard_bits) {
+        fa.sh_bits = pl.shard_bits;
+        fa.sh_nl = pl.NL;
+        fa.sh_rank_first = pl.rank_first;
+        fa.sh_self = pl.shard_self ? 1 : 0;
+        for (int k = 0; k < pl.shard_bits; ++k) fa.sh_rem[k] = pl.shard_self ? nullptr : static_cast<const double2*>(rt.shard_recv[k]);
+        shard_groups(pl, fa.sh_grp);
+        for (int q = 0; q < fa.g.ga; ++q) fa.g.amask[q] &= uint32_t(pl.dim - 1);  // in-slab flips only; the rank bits are the partner slabs
+    }
     dim3 grid(unsigned((pl.dim + 255) / 256), pl.B);
     if (direct_global_ok(rt)) {
         if (obs && expect_slot) {
@@ -1334,8 +1402,9 @@ uint32_t to_tile_mask(const LayoutDesc& d, uint32_t index_mask) {
 }
 
 bool chain_enabled(const Runtime& rt) {
-    const int N = rt.pl.N;
+    const int N = rt.pl.NL;
     if (rt.variant == 1 || rt.pl.n_pair) return false;  // pair terms: direct kernels
+    if (rt.pl.shard_bits) return N > kTileBits && N <= 22;  // sharded: the two-layout chain on the slab qubits
     return N > kTileBits && N <= 28 && !rt.prefer_direct;
 }
 
@@ -1413,14 +1482,14 @@ struct BatchSlice {
 
 int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, const BatchSlice& bs, const InjectSource& inj, hipStream_t stream) {
     const Plan& pl = rt.pl;
-    const LayoutDesc X = chain_layout(pl.N, cs.layout, rt.force_three);
+    const LayoutDesc X = chain_layout(pl.NL, cs.layout, rt.force_three);
     ChainArgs ca{};
     ca.u = cs.u;
     ca.p = cs.p;
     ca.v_out = cs.v_out;
     ca.q_out = cs.q_out;
     {
-        const size_t per_layout = kTileAmps + size_t(pl.dim >> kTileBits) * 16;
+        const size_t per_layout = kTileAmps + size_t((size_t(1) << pl.N) >> kTileBits) * 16;
         const double* split = reinterpret_cast<const double*>(ws + pl.off_split) + size_t(cs.layout) * per_layout;
         ca.utt = split;
         ca.vr = split + kTileAmps;
@@ -1461,6 +1530,16 @@ int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, const BatchSl
     ca.expect_slot = cs.expect_slot;
     ca.n_obs = cs.n_obs;
     ca.exp_ostride = cs.exp_ostride;
+    ca.obs_bstride = pl.shard_bits ? long(pl.dim) : 0;
+    ca.obs_ostride = pl.shard_bits ? long(pl.B) * long(pl.dim) : long(pl.dim);
+    if (pl.shard_bits) {
+        ca.sh_bits = pl.shard_bits;
+        ca.sh_nl = pl.NL;
+        ca.sh_rank_first = pl.rank_first;
+        ca.sh_self = pl.shard_self ? 1 : 0;
+        for (int k = 0; k < pl.shard_bits; ++k) ca.sh_rem[k] = pl.shard_self ? nullptr : static_cast<const double2*>(rt.shard_recv[k]);
+        shard_groups(pl, ca.sh_grp);
+    }
     if (cs.bwd) {
         double* ge = reinterpret_cast<double*>(ws + pl.off_ge);
         const long ge_rec = long(kGradReplicas) * (pl.NC + 1);
@@ -1510,8 +1589,10 @@ int run_chain(const Runtime& rt, char* ws, const std::vector<ChainItem>& items, 
     const int F = int(items.size()) - (skip_last_finish ? 1 : 0);  // the last factor is not even started then
     if (F <= 0) return RYDIFF_OK;
     std::vector<KernelStep> ks;
-    chain_schedule(pl.N, rt.force_three, F, ks);
+    chain_schedule(pl.NL, rt.force_three, F, ks);
     const double2* cur = start;
+    int rcx = shard_signal(rt, 0, cur);  // partners need the chain's start vector for the first completing launch
+    if (rcx) return rcx;
     const InjectSource no_inj{};
     // L2-resident placement: partials are rewritten IN PLACE (a workgroup reads and writes only its own tile elements), so
     // the live set of a trajectory is one complete vector + one partial
@@ -1539,10 +1620,16 @@ int run_chain(const Runtime& rt, char* ws, const std::vector<ChainItem>& items, 
         }
         cs.sta_stage = cs.has_q ? items[st.sta].stage : -1;
         if (cs.has_q) cs.sta = items[st.sta].s;
-        int rc = launch_chain(rt, ws, cs, bs, no_inj, stream);
+        int rc = cs.has_p ? shard_signal(rt, 1, nullptr) : RYDIFF_OK;  // this launch reads the partners' copies of `cur`
+        if (rc) return rc;
+        rc = launch_chain(rt, ws, cs, bs, no_inj, stream);
         if (rc) return rc;
         if (cs.has_p && st.completes) {
             cur = cs.v_out;
+            if (k + 1 < ks.size()) {  // the next launch completes the next factor from the partners' copies of this vector
+                rc = shard_signal(rt, 0, cur);
+                if (rc) return rc;
+            }
             rc = on_done(st.fin, cs.v_out);
             if (rc) return rc;
         }
@@ -1563,7 +1650,7 @@ int run_chain_bwd(const Runtime& rt, char* ws, const std::vector<ChainItem>& ite
     double2* pp[2] = {reinterpret_cast<double2*>(ws + pl.off_pp0), reinterpret_cast<double2*>(ws + pl.off_pp1)};
     const int M = int(items.size());
     std::vector<KernelStep> ks;
-    chain_schedule(pl.N, rt.force_three, M, ks);
+    chain_schedule(pl.NL, rt.force_three, M, ks);
     const double2* cur = lam_in;
     auto ppsel = [&](size_t k) { return bs.xcd ? pp[0] : pp[k & 1]; };
     // adjoint factor index a = 0..M-1 corresponds to forward factor f = M-1-a
@@ -1627,7 +1714,7 @@ int run_chain_bwd(const Runtime& rt, char* ws, const std::vector<ChainItem>& ite
 }
 
 // ---- persistent small-N forward (k_persist) ------------------------------------------------------------------------
-bool persist_enabled(const Runtime& rt) { return rt.variant != 1 && rt.pl.N <= kTileBits; }
+bool persist_enabled(const Runtime& rt) { return rt.variant != 1 && rt.pl.N <= kTileBits && !rt.pl.shard_bits; }
 
 template <int LT, bool CPLX>
 int launch_persist_t(const PersistArgs& pa, int B, hipStream_t stream) {
@@ -1800,7 +1887,7 @@ namespace {
 // group size (0: off).  Placement changes speed only: results are the same as with the plain grid (A/B-tested).
 int xcd_group_size(const Runtime& rt, bool adjoint) {
     const Plan& pl = rt.pl;
-    if (!chain_enabled(rt) || chain_layout_count(pl.N, rt.force_three) != 2) return 0;
+    if (!chain_enabled(rt) || chain_layout_count(pl.N, rt.force_three) != 2 || pl.shard_bits) return 0;
     const size_t live = size_t(32) << pl.N;    // complete vector + partial of one trajectory
     const size_t budget = size_t(3) << 20;     // of the 4 MiB L2 (the rest: tape lines on their way out, tables)
     const int m = int(std::max<size_t>(1, budget / live));
@@ -1887,6 +1974,15 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
     double2* buf[2] = {reinterpret_cast<double2*>(ws + pl.off_buf0), reinterpret_cast<double2*>(ws + pl.off_buf1)};
     const bool full_ws_tape = pl.tape_mode == 2;  // (prepare downgrades the request where the full tape is not possible)
     double2* sout = static_cast<double2*>(states_out);
+    // final_state_only: no per-step states; the state at the last evaluation time is copied to states_out at the end
+    double2* final_dst = nullptr;
+    if (p->final_state_only && states_out) {
+        if (need_tape || persist_enabled(rt))
+            return fail(RYDIFF_EINVAL, "final_state_only needs the launch-per-factor kernels (more than 12 qubits or a sharded run) and no tape");
+        final_dst = sout;
+        sout = nullptr;
+        states_out = nullptr;
+    }
     double2* tape = (states_out && !full_ws_tape) ? sout : (pl.tape_mode ? reinterpret_cast<double2*>(ws + pl.off_tape) : nullptr);
     double2* copy_out = (states_out && full_ws_tape) ? sout : nullptr;  // states at the save points, copied from the full tape
     const double2* cur = static_cast<const double2*>(psi0);
@@ -1898,9 +1994,11 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
     const double* obs = p->obs_diag;
     const bool want_exp = expect_out && pl.n_obs > 0;
     const unsigned red_blocks = unsigned(std::min<size_t>((pl.dim + 255) / 256, 1024));
+    const long obs_bstride = pl.shard_bits ? long(pl.dim) : 0;  // sharded: one observable slab per rank
     if (want_exp) {
         HIP_TRY(hipMemsetAsync(expect_out, 0, size_t(pl.n_obs) * (pl.T + 1) * pl.B * sizeof(double), stream));
-        hipLaunchKernelGGL(k_expect_diag, dim3(red_blocks, pl.B), dim3(256), 0, stream, cur, obs, expect_out, pl.n_obs, pl.T + 1, 0, pl.B, uint32_t(pl.dim));
+        hipLaunchKernelGGL(k_expect_diag, dim3(red_blocks, pl.B), dim3(256), 0, stream, cur, obs, expect_out, pl.n_obs, pl.T + 1, 0, pl.B, uint32_t(pl.dim),
+                           obs_bstride);
         LAUNCH_CHECK();
     }
     std::vector<ChainItem> chain;
@@ -1959,6 +2057,9 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
                 return buf[flip];
             };
             auto done = [&](int i, const double2* out) -> int {
+                if (final_dst && step_of_end[i] == pl.T)
+                    HIP_TRY(hipMemcpyAsync(final_dst + size_t(bs.first) * pl.dim, out + size_t(bs.first) * pl.dim,
+                                           size_t(bs.count) * pl.dim * sizeof(double2), hipMemcpyDeviceToDevice, stream));
                 if (copy_out && step_of_end[i])
                     HIP_TRY(hipMemcpyAsync(copy_out + size_t(step_of_end[i]) * sv + size_t(bs.first) * pl.dim, out + size_t(bs.first) * pl.dim,
                                            size_t(bs.count) * pl.dim * sizeof(double2), hipMemcpyDeviceToDevice, stream));
@@ -1994,6 +2095,9 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
                 pp ^= 1;
             }
             const bool want_here = want_exp && last;  // the launch that completes the step also reduces <O> where it can
+            rc = shard_signal(rt, 0, cur);  // sharded: partners need `cur` ...
+            if (!rc) rc = shard_signal(rt, 1, nullptr);  // ... and this launch reads theirs
+            if (rc) return rc;
             rc = launch_factor(rt, ws, cur, dst, chain[i].stage, chain[i].s, stream, want_here ? obs : nullptr,
                                want_here ? expect_out + size_t(k + 1) * pl.B : nullptr, &exp_fused);
             if (rc) return rc;
@@ -2001,10 +2105,12 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
         }
         if (copy_out) HIP_TRY(hipMemcpyAsync(copy_out + size_t(k + 1) * sv, cur, pl.state_bytes, hipMemcpyDeviceToDevice, stream));
         if (want_exp && !exp_fused) {
-            hipLaunchKernelGGL(k_expect_diag, dim3(red_blocks, pl.B), dim3(256), 0, stream, cur, obs, expect_out, pl.n_obs, pl.T + 1, k + 1, pl.B, uint32_t(pl.dim));
+            hipLaunchKernelGGL(k_expect_diag, dim3(red_blocks, pl.B), dim3(256), 0, stream, cur, obs, expect_out, pl.n_obs, pl.T + 1, k + 1, pl.B, uint32_t(pl.dim),
+                               obs_bstride);
             LAUNCH_CHECK();
         }
     }
+    if (final_dst) HIP_TRY(hipMemcpyAsync(final_dst, cur, pl.state_bytes, hipMemcpyDeviceToDevice, stream));
     return RYDIFF_OK;
 }
 

@@ -321,6 +321,142 @@ def run_distributed(prob: ShardedProblem, psi0_local: Tensor, tsave, group=None,
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# natively driven forward run: ONE call of rydiff_forward runs every step and every factor pass of the sharded trajectory
+# (include/rydiff.h, RydProblem.shard_bits); Python only posts the slab exchanges when the library asks for them.
+# ---------------------------------------------------------------------------------------------------------------------
+def _native_forward(prob: ShardedProblem, psi_slabs: Tensor, tsave, rank_first: int, obs_slabs: Optional[Tensor],
+                    recv: Optional[list], exchange: Optional[Callable], lookup: Optional[list] = None) -> tuple[Tensor, Optional[Tensor], dict]:
+    """psi_slabs: (ranks_here, 2^(N-g)) on the GPU; obs_slabs: (ranks_here, 2^(N-g)) or None.  Returns the final slabs, the
+    PARTIAL <O>(t_k) summed over the slabs of this call (n_tsave,) and the plan statistics."""
+    from . import _native
+
+    L = _native.lib()
+    dev = psi_slabs.device
+    ts = np.ascontiguousarray(np.asarray(tsave, dtype=np.float64))
+    amp = torch.as_tensor(np.ascontiguousarray(prob.amp_tables, dtype=np.complex128)).reshape(1, -1, prob.amp_tables.shape[-1]).to(dev) \
+        if prob.amp_tables.size else torch.zeros(1, 0, 2, dtype=torch.complex128, device=dev)
+    det = torch.as_tensor(np.ascontiguousarray(prob.det_tables, dtype=np.float64)).reshape(1, -1, prob.det_tables.shape[-1]).to(dev) \
+        if prob.det_tables.size else torch.zeros(1, 0, 2, dtype=torch.float64, device=dev)
+    u = torch.as_tensor(np.ascontiguousarray(prob.u_pairs, dtype=np.float64)).to(dev)
+    amp_masks = np.asarray(prob.amp_masks, dtype=np.uint32)
+    det_masks = np.asarray(prob.det_masks, dtype=np.uint32)
+    psi = psi_slabs.to(torch.complex128).contiguous()
+    ranks_here, dloc = psi.shape
+    p = _native.RydProblem()
+    p.n_qubits, p.batch, p.coeff_batch = prob.n_qubits, ranks_here, 1
+    p.n_samples = int(amp.shape[-1] if len(amp_masks) else det.shape[-1])
+    p.dt = prob.dt
+    p.n_amp_terms, p.n_det_terms = len(amp_masks), len(det_masks)
+    p.amp_masks = amp_masks.ctypes.data if len(amp_masks) else None
+    p.det_masks = det_masks.ctypes.data if len(det_masks) else None
+    p.amp_tables = amp.data_ptr() if len(amp_masks) else None
+    p.det_tables = det.data_ptr() if len(det_masks) else None
+    p.u_pairs = u.data_ptr() if u.numel() else None
+    p.n_tsave, p.tsave = len(ts), ts.ctypes.data
+    p.solver, p.tol = _native.SOLVER_KRYLOV_SE, prob.tol
+    obs = None
+    if obs_slabs is not None:
+        obs = obs_slabs.to(torch.float64).contiguous().reshape(1, ranks_here, dloc)
+        p.n_obs, p.obs_diag = 1, obs.data_ptr()
+    p.kernel_variant = _native.default_kernel_variant()
+    p.shard_bits, p.shard_rank_first, p.final_state_only = prob.n_gpu_bits, rank_first, 1
+    keep = [amp, det, u, amp_masks, det_masks, ts, obs]
+    if recv is not None:
+        ptrs = (ctypes.c_void_p * len(recv))(*[r.data_ptr() for r in recv])
+        cb = _native.SHARD_EXCHANGE_FN(exchange)
+        p.shard_recv = ctypes.cast(ptrs, ctypes.c_void_p)
+        p.shard_exchange = ctypes.cast(cb, ctypes.c_void_p)
+        keep += [ptrs, cb]
+    with torch.cuda.device(dev):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        scratch = torch.empty(_native.PLAN_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
+        info = _native.RydPlanInfo()
+        _native.check(L.rydiff_plan(ctypes.byref(p), 0, 0, ctypes.c_void_p(scratch.data_ptr()), stream, ctypes.byref(info)))
+        workspace = torch.empty(info.workspace_bytes, dtype=torch.uint8, device=dev)
+        final = torch.empty_like(psi)
+        expect = torch.zeros(1, len(ts), ranks_here, dtype=torch.float64, device=dev) if obs is not None else None
+        keep.append(workspace)
+        if lookup is not None:  # the exchange callback looks the slab tensors up by address
+            lookup[:] = [psi, workspace]
+        _native.check(L.rydiff_forward(ctypes.byref(p), ctypes.byref(info), ctypes.c_void_p(psi.data_ptr()), ctypes.c_void_p(final.data_ptr()),
+                                       ctypes.c_void_p(expect.data_ptr()) if expect is not None else None,
+                                       ctypes.c_void_p(workspace.data_ptr()), workspace.numel(), 0, stream))
+    stats = {"degree": info.degree, "total_factors": info.total_factors, "kernel_family": _native.KERNEL_FAMILIES[info.kernel_family],
+             "spectral": (info.spectral_lo, info.spectral_hi)}
+    return final, (expect[0].sum(dim=1) if expect is not None else None), stats
+
+
+def run_virtual_native(prob: ShardedProblem, psi0: Tensor, tsave, obs_diag: Optional[Tensor] = None):
+    """All 2^g ranks on this device, the whole trajectory in ONE native call (partners are read in place).
+    Returns (final state (2^N,), <O>(t_k) or None, stats)."""
+    dloc = 1 << prob.n_local
+    final, expect, stats = _native_forward(prob, psi0.reshape(prob.world, dloc), tsave, 0,
+                                           None if obs_diag is None else obs_diag.reshape(prob.world, dloc), None, None)
+    return final.reshape(-1), expect, stats
+
+
+def run_distributed_native(prob: ShardedProblem, psi0_local: Tensor, tsave, group=None, obs_diag_local: Optional[Tensor] = None):
+    """One process per GPU: the library runs the whole trajectory of this rank's slab in one call and asks — through the
+    exchange callback — for the hypercube slab exchange before every completing pass (one isend / irecv pair per partner =
+    one xGMI link each, posted together); <O>(t_k) is all-reduced once at the end.  Returns (final slab, <O>(t_k), stats)."""
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if world != prob.world:
+        raise ValueError(f"world size {world} != 2^{prob.n_gpu_bits}")
+    g = prob.n_gpu_bits
+    recv = [torch.empty_like(psi0_local, dtype=torch.complex128) for _ in range(g)]  # recv[k]: slab of rank ^ (1 << k)
+    state = {"works": [], "error": None, "staged": []}
+    lookup: list = []
+    via_host = dist.get_backend(group) == "gloo"  # tests on one GPU: gloo moves host buffers
+
+    def view_of(addr: int, nbytes: int) -> Tensor:
+        for t in lookup:
+            base = t.data_ptr()
+            if base <= addr and addr + nbytes <= base + t.numel() * t.element_size():
+                flat = t.reshape(-1).view(torch.uint8)
+                return flat[addr - base: addr - base + nbytes].view(torch.complex128)
+        raise RuntimeError("exchange callback: slab address outside the known buffers")
+
+    def exchange(_user, phase, src, nbytes):
+        try:
+            if phase == 0:
+                x = view_of(src, nbytes)
+                if via_host:
+                    x = x.cpu()  # (synchronises: fine for the gloo tests)
+                    state["staged"] = [torch.empty_like(x) for _ in range(g)]
+                bufs = state["staged"] if via_host else recv
+                reqs = []
+                for k in range(g):  # hypercube neighbours: all links in flight together
+                    partner = rank ^ (1 << k)
+                    reqs.append(dist.P2POp(dist.isend, x, partner, group))
+                    reqs.append(dist.P2POp(dist.irecv, bufs[k], partner, group))
+                state["works"] = dist.batch_isend_irecv(reqs)
+            else:
+                for w in state["works"]:
+                    w.wait()  # NCCL: the current stream waits; gloo: the host waits
+                state["works"] = []
+                if via_host:
+                    for k in range(g):
+                        recv[k].copy_(state["staged"][k])
+            return 0
+        except Exception as exc:  # reported after the native call returns
+            state["error"] = exc
+            return 1
+
+    try:
+        final, expect, stats = _native_forward(prob, psi0_local.reshape(1, -1), tsave, rank,
+                                               None if obs_diag_local is None else obs_diag_local.reshape(1, -1), recv, exchange, lookup)
+    except RuntimeError:
+        if state["error"] is not None:
+            raise state["error"]
+        raise
+    if expect is not None:
+        dist.all_reduce(expect, op=dist.ReduceOp.SUM, group=group)  # the scalar reduction of the sharded run, once
+    return final.reshape(-1), expect, stats
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # gradients: exact discrete adjoint of the sharded factor chain
 # ---------------------------------------------------------------------------------------------------------------------
 class _VirtualFabric:

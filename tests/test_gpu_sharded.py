@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import restatement as R
-from pulser_diff_amd.sharded import ShardedProblem, grad_virtual, run_virtual
+from pulser_diff_amd.sharded import ShardedProblem, grad_virtual, run_virtual, run_virtual_native
 from tests.helpers import mask_of, random_terms, rel_err, to_native
 
 pytestmark = pytest.mark.gpu
@@ -70,3 +70,90 @@ def test_virtual_sharded_gradients_match_single_gpu_adjoint(cuda_device, n_qubit
     assert rel_err(out["g_amp"], amp.grad[0].cpu().numpy()) < 1e-9
     assert rel_err(out["g_det"], det.grad[0].cpu().numpy()) < 1e-9
     assert rel_err(out["g_u"], u.grad.cpu().numpy()) < 1e-9
+
+
+@pytest.mark.parametrize("n_qubits,g,variant", [(5, 1, 0), (8, 3, 0), (12, 2, 0), (14, 1, 0), (15, 2, 0), (16, 3, 0), (17, 3, 4), (16, 2, 1)])
+def test_native_sharded_run_matches_single_gpu_solver(cuda_device, n_qubits, g, variant):
+    """K6: the WHOLE sharded trajectory in one native call (RydProblem.shard_bits): slabs as trajectories, the rank qubits'
+    flips read from the partner slabs, diagonal at the global index — direct kernels for slabs of <= 12 qubits, the chained
+    LDS-tile passes beyond — against the un-sharded solver on the same register: final state and <sum Z>(t_k)."""
+    from pulser_diff_amd import _native
+    from pulser_diff_amd.solver import SolverType, evolve
+
+    terms, prob = _problem(n_qubits, g, seed=500 + n_qubits)
+    tsave = torch.linspace(0, 0.02, 6, dtype=torch.float64)
+    gen = torch.Generator().manual_seed(n_qubits)
+    psi0 = torch.randn(2**n_qubits, generator=gen, dtype=torch.complex128)
+    psi0 = (psi0 / psi0.norm()).to(cuda_device)
+    zd = R.total_magnetization_diag(n_qubits).to(cuda_device)
+    amp, det, u, spec = to_native(terms, cuda_device, SolverType.KRYLOV_SE)
+    states, expect = evolve(amp, det, u, tsave, psi0[None], spec, zd[None])
+    _native.set_kernel_variant(variant)
+    try:
+        final, e_sh, stats = run_virtual_native(prob, psi0, tsave.numpy(), obs_diag=zd)
+    finally:
+        _native.set_kernel_variant(0)
+    assert stats["kernel_family"] == ("chained-tiles" if (n_qubits - g > 12 and variant != 1) else "direct")
+    assert rel_err(final.cpu().numpy(), states[-1, 0].cpu().numpy()) < 1e-11
+    assert np.abs(e_sh.cpu().numpy() - expect[0, :, 0].cpu().numpy()).max() < 1e-10
+
+
+def _two_rank_worker(rank, world, port, n_qubits, g, seed, out_q):
+    import os
+
+    import torch.distributed as dist
+
+    from pulser_diff_amd.sharded import run_distributed_native
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)  # every rank on the box's one GPU; gloo carries the slabs
+        terms, prob = _problem(n_qubits, g, seed=seed)
+        tsave = np.linspace(0, 0.02, 6)
+        gen = torch.Generator().manual_seed(n_qubits)
+        psi0 = torch.randn(2**n_qubits, generator=gen, dtype=torch.complex128)
+        psi0 = psi0 / psi0.norm()
+        dloc = 2 ** (n_qubits - g)
+        zd = R.total_magnetization_diag(n_qubits)
+        final, expect, stats = run_distributed_native(prob, psi0[rank * dloc:(rank + 1) * dloc].to(dev), tsave,
+                                                      obs_diag_local=zd[rank * dloc:(rank + 1) * dloc].to(dev))
+        out_q.put((rank, final.cpu().numpy(), expect.cpu().numpy(), stats["kernel_family"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_qubits,g", [(9, 1), (15, 2)])
+def test_native_sharded_run_over_processes(cuda_device, n_qubits, g):
+    """The same native run with the ranks in SEPARATE processes (one slab each; here all on the one GPU, gloo as transport): the
+    library drives the whole trajectory and calls back for the hypercube slab exchange (RydProblem.shard_exchange)."""
+    import socket
+
+    import torch.multiprocessing as mp
+    from pulser_diff_amd.solver import SolverType, evolve
+
+    world = 2**g
+    with socket.socket() as sck:
+        sck.bind(("127.0.0.1", 0))
+        port = sck.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, n_qubits, g, 700 + n_qubits, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    results = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    terms, prob = _problem(n_qubits, g, seed=700 + n_qubits)
+    gen = torch.Generator().manual_seed(n_qubits)
+    psi0 = torch.randn(2**n_qubits, generator=gen, dtype=torch.complex128)
+    psi0 = (psi0 / psi0.norm()).to(cuda_device)
+    zd = R.total_magnetization_diag(n_qubits).to(cuda_device)
+    amp, det, u, spec = to_native(terms, cuda_device, SolverType.KRYLOV_SE)
+    states, expect = evolve(amp, det, u, torch.linspace(0, 0.02, 6, dtype=torch.float64), psi0[None], spec, zd[None])
+    final = np.concatenate([r[1] for r in results])
+    assert rel_err(final, states[-1, 0].cpu().numpy()) < 1e-11
+    for r in results:  # every rank holds the all-reduced expectation values
+        assert np.abs(r[2] - expect[0, :, 0].cpu().numpy()).max() < 1e-10
+        assert r[3] == ("chained-tiles" if n_qubits - g > 12 else "direct")
