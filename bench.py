@@ -58,6 +58,7 @@ def parse_args():
     ap.add_argument("--time-steps", type=int, default=0, help="override the number of time steps (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c4-reference", action="store_true", help="N=1 default run: skip the secondary single-GPU c4 figure")
+    ap.add_argument("--no-c5-leg", action="store_true", help="default run: skip the secondary state-sharded (c5) figure")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (RydProblem.kernel_variant); 0 = automatic")
     return ap.parse_args()
@@ -169,7 +170,10 @@ def run_rank(args) -> None:
         device = torch.device("cuda", local_rank)
         torch.cuda.set_device(device)
         if world > 1:
-            dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+            import datetime
+
+            # "nccl" is RCCL on ROCm; a rank that gets stuck fails the job after 5 minutes instead of hanging it
+            dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=300))
 
     def barrier():
         if world > 1:
@@ -181,6 +185,17 @@ def run_rank(args) -> None:
         out = run_c5(args, rank, world, device, barrier)
     else:
         out = run_trajectories(args, workload, rank, world, device, barrier)
+        # Secondary figure of the DEFAULT line: BASELINE config 5 (24 qubits, the state sharded over the ranks; on one GPU: 8
+        # virtual ranks) — a short run (20 of its 100 steps), never part of `value`.  A power-of-two rank count is needed; any
+        # failure is reported in the field instead of taking the headline measurement down.
+        if args.workload == "auto" and not STANDIN and not args.no_c5_leg and world & (world - 1) == 0:
+            sub = argparse.Namespace(**vars(args))
+            sub.steps, sub.warmup, sub.time_steps = 1, 1, 20
+            try:
+                r5 = run_c5(sub, rank, world, device, barrier)
+                out["c5_state_sharded"] = {k: r5[k] for k in ("value", "unit", "ms_per_step", "config", "final_norm", "roofline", "link")}
+            except Exception as exc:  # noqa: BLE001
+                out["c5_state_sharded"] = {"error": repr(exc)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -399,7 +414,9 @@ def run_trajectories(args, workload: str, rank: int, world: int, device, barrier
                                    f"{(total_factors + 1) * 16 * dim * bsz / 2**30:.0f} GiB of HBM hold every factor output, so the sweep "
                                    "recomputes nothing; with one state per save point (N=20 with B>=2, or a second tenant) it needs a recompute pass per factor"}
     if workload == "c3" and world == 1 and rank == 0 and not args.no_c4_reference:
+        torch.cuda.empty_cache()  # hand the c3 run's 156 GiB tape block back before the c4 chunks allocate theirs
         out["c4_single_gpu"] = c4_reference(args)
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and workload in ("c3", "c2", "c1", "c4", "tiny"):
         try:
             out["cpu_baseline"] = cpu_baseline(workload, n_qubits, coords, T, seg_len, omega.detach().cpu()[0], delta.detach().cpu()[0],

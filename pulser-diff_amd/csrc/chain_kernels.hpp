@@ -330,10 +330,12 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
         xg[r] = xbase | (i & lomask) | ((i >> a.lo) << a.hs);
         uu[r] = ld(a.u + boff + xg[r]);
     }
-    if (a.has_p) {
+    // Loads OUTSIDE of control flow (the host passes valid pointers even for a chain's first / last launch, where the values are
+    // not used): the compiler then places the wait counters per use — the tile write waits for u only, the partial is awaited
+    // where it is accumulated, after the finish stage's partner sums — instead of conservatively at the join of the branches
+    // (measured on the 20-qubit pass: 14.16 -> 13.91 us forward, fwd+grad +2.9 %; profiles/r02_uncond_loads_ab.txt).
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = ld(a.p + boff + xg[r]);
-    }
+    for (int r = 0; r < R; ++r) acc[r] = ld(a.p + boff + xg[r]);
     // sharded runs: flips of the rank qubits = the partner slabs' complete v_{j-1} at the same local index, times
     // beta * (c or conj c).  Requested together with u and p so that all of a tile's global loads are in flight at once.
     double2 remacc[R];
@@ -355,18 +357,16 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
         }
     }
     double dg[R];  // tile-local part of the interaction diagonal (32 KiB table shared by all tiles: L2-resident)
-    if (a.has_q) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) dg[r] = a.utt[unsigned(r) * NT + tid];
-    }
+    for (int r = 0; r < R; ++r) dg[r] = a.utt[unsigned(r) * NT + tid];
     double2 xf[R], xs[R];
-    if (BWD && a.has_p) {
+    // the real-drive adjoint (no signed sums) has the registers to request the second tape vector up front as well
+    constexpr bool XS_EARLY = BWD && !CPLX;
+    if (BWD) {
 #pragma unroll
         for (int r = 0; r < R; ++r) xf[r] = stream_load(a.x_fin + boff + xg[r]);
     }
-    // the real-drive adjoint (no signed sums) has the registers to request the second tape vector up front as well
-    constexpr bool XS_EARLY = BWD && !CPLX;
-    if (XS_EARLY && a.has_q) {
+    if (XS_EARLY) {
 #pragma unroll
         for (int r = 0; r < R; ++r) xs[r] = stream_load(a.x_sta + boff + xg[r]);
     }

@@ -1485,7 +1485,7 @@ int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, const BatchSl
     const LayoutDesc X = chain_layout(pl.NL, cs.layout, rt.force_three);
     ChainArgs ca{};
     ca.u = cs.u;
-    ca.p = cs.p;
+    ca.p = cs.p ? cs.p : cs.u;  // (always loadable: the kernel requests u, p and the tape vectors outside of control flow)
     ca.v_out = cs.v_out;
     ca.q_out = cs.q_out;
     {
@@ -1543,8 +1543,8 @@ int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, const BatchSl
     if (cs.bwd) {
         double* ge = reinterpret_cast<double*>(ws + pl.off_ge);
         const long ge_rec = long(kGradReplicas) * (pl.NC + 1);
-        ca.x_fin = cs.x_fin;
-        ca.x_sta = cs.x_sta;
+        ca.x_fin = cs.x_fin ? cs.x_fin : cs.u;
+        ca.x_sta = cs.x_sta ? cs.x_sta : cs.u;
         ca.ge_fin = ge + size_t(std::max(cs.fin_stage, 0)) * ge_rec;
         ca.ge_sta = ge + size_t(std::max(cs.sta_stage, 0)) * ge_rec;
         ca.ge_bstride = pl.Bc > 1 ? long(pl.stages.size()) * ge_rec : 0;
