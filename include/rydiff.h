@@ -59,7 +59,7 @@ extern "C" {
 #endif
 
 #define RYDIFF_MAX_QUBITS 30
-#define RYDIFF_MAX_PAIR_TERMS 15
+#define RYDIFF_MAX_PAIR_TERMS 28
 #define RYDIFF_MAX_TERMS 64
 
 enum { RYDIFF_OK = 0, RYDIFF_EINVAL = -1, RYDIFF_EWORKSPACE = -2, RYDIFF_EHIP = -3, RYDIFF_ENOTIMPL = -4 };

@@ -336,6 +336,77 @@ def reference_style_H_t(terms: HamTerms) -> Callable[[float], Tensor]:
     return H_t
 
 
+# ---- literal restatement for ALL two-level bases of the reference (ground-rydberg, digital, XY): dense, small registers ----
+C3_MOCK_DEVICE = 3700.0  # pulser MockDevice interaction_coeff_xy, rad/us*um^3 (as recalled; no stored output pins the XY mode)
+
+
+def reference_style_dense_H_t(coords: Tensor, amp_terms: list, det_terms: list, dt: float, n_samples: int, basis_name: str,
+                              c6: float = C6_MOCK_DEVICE, c3: float = C3_MOCK_DEVICE, magnetic_field=(0.0, 0.0, 30.0)):
+    """Literal, dense restatement of the reference's Hamiltonian for a two-level basis (small registers; test infrastructure):
+
+      hamiltonian.py:288-318  basis order and projectors: ground-rydberg (r, g), digital (g, h), XY (u, d);
+      hamiltonian.py:406-416  the amplitude term drives sigma_gr / sigma_hg / sigma_du = |1><0|, the detuning term weights
+                              sigma_rr / sigma_gg / sigma_uu = |0><0|, with coefficients 0.5*amp*exp(-i*phase), -0.5*det;
+      hamiltonian.py:333-344  van der Waals term U = 0.5*C6/r^6 on sigma_rr(q1) sigma_rr(q2)      (ground-rydberg only, :460);
+      hamiltonian.py:346-366  XY term U = 0.5*C3*(1 - 3 cos^2)/r^3 on sigma_ud(q1) sigma_du(q2)     (XY only);
+      hamiltonian.py:526-546  H(t) = 2*int_mat + sum_terms (M c(t) + (M c(t))^dagger) with the interpolation rule.
+
+    Note `2 * int_mat` (hamiltonian.py:536): the interaction term gets NO `+ adjoint()`, so in the XY mode the exchange is
+    one-directional and H(t) is not Hermitian — restated as written.  amp_terms / det_terms: [(coefficient array, qubits)]."""
+    coords = torch.as_tensor(coords, dtype=RDTYPE)
+    n = coords.shape[0]
+    ket0, ket1 = torch.tensor([[1.0], [0.0]], dtype=CDTYPE), torch.tensor([[0.0], [1.0]], dtype=CDTYPE)
+    eye = torch.eye(2, dtype=CDTYPE)
+    lower, proj0, raise_ = ket1 @ ket0.mH, ket0 @ ket0.mH, ket0 @ ket1.mH  # |1><0| (gr / hg / du), |0><0| (rr / gg / uu), |0><1| (ud)
+
+    def build(ops: dict) -> Tensor:  # build_operator, hamiltonian.py:221-268
+        out = torch.ones(1, 1, dtype=CDTYPE)
+        for q in range(n):
+            out = torch.kron(out, ops.get(q, eye))
+        return out
+
+    dim = 2**n
+    int_mat = torch.zeros(dim, dim, dtype=CDTYPE)
+    if basis_name != "digital" and n > 1:
+        for q1, q2 in itertools.combinations(range(n), 2):
+            dist = torch.linalg.norm(coords[q1] - coords[q2])
+            if basis_name == "XY":
+                mag = torch.as_tensor(magnetic_field, dtype=RDTYPE)[: coords.shape[1]]
+                mag_norm = torch.linalg.norm(mag)
+                cosine = 0.0 if mag_norm < 1e-8 else torch.dot(coords[q1] - coords[q2], mag) / (dist * mag_norm)
+                u = 0.5 * c3 * (1 - 3 * cosine**2) / dist**3
+                int_mat = int_mat + u * build({q1: raise_, q2: lower})  # sigma_ud(q1) sigma_du(q2)
+            else:
+                int_mat = int_mat + (0.5 * c6 / dist**6) * build({q1: proj0, q2: proj0})
+    amp_mats = [(sum(build({q: lower}) for q in tg), c) for c, tg in amp_terms]
+    det_mats = [(sum(build({q: proj0}) for q in tg), c) for c, tg in det_terms]
+
+    def H_t(t):
+        if not isinstance(t, Tensor):
+            t = torch.tensor(t, dtype=RDTYPE)
+        i1, i2 = interp_indices(float(t), dt, n_samples)
+        ham = 2 * int_mat
+        for mat, val in det_mats:
+            ham_mat = mat * ((1.0 + 0.0j) * (val[i1] + (val[i2] - val[i1]) * (t - i1 * dt) / dt))
+            ham = ham + ham_mat + ham_mat.mH
+        for mat, val in amp_mats:
+            ham_mat = mat * (val[i1] + (val[i2] - val[i1]) * (t - i1 * dt) / dt)
+            ham = ham + ham_mat + ham_mat.mH
+        return ham
+
+    return H_t
+
+
+def krylov_map_from_dense_H(H_t: Callable, psi0: Tensor, tsave: Tensor) -> Tensor:
+    """KRYLOV_SE semantics on an explicit dense H(t) (which need not be Hermitian): exp(-i H(t_{k+1}) dt) psi_k."""
+    states = [psi0]
+    psi = psi0
+    for k in range(len(tsave) - 1):
+        psi = torch.linalg.matrix_exp(-1j * H_t(tsave[k + 1]) * (tsave[k + 1] - tsave[k])) @ psi
+        states.append(psi)
+    return torch.stack(states)
+
+
 # --------------------------------------------------------------------------------------
 # Initial state / observables (backend.py:253-280, utils.py:47-86)
 # --------------------------------------------------------------------------------------

@@ -173,8 +173,10 @@ class TorchEmulator:
         """backend.py:253-280: "all-ground" or a (dim[, B]) tensor."""
         n = self._hamiltonian._size
         if isinstance(state, str) and state == "all-ground":
+            # kron of N |g> kets: |g> is basis state 1 of the ground-rydberg basis (r, g) -> last vector; it is basis state 0
+            # of the digital basis (g, h), like |u> of the XY basis (u, d) (backend.py:266-271) -> first vector
             psi = torch.zeros(2**n, 1, dtype=torch.complex128)
-            psi[-1, 0] = 1.0  # kron of N |g> kets = last basis vector (r=0, g=1)
+            psi[-1 if self._hamiltonian.basis_name == "ground-rydberg" else 0, 0] = 1.0
             self._initial_state = psi
         else:
             shape = state.shape[0]
@@ -266,6 +268,9 @@ class TorchEmulator:
         """
         if time_grad:
             self._eval_times_array.requires_grad_(True)  # backend.py:453-455
+        if dist_grad and self._hamiltonian._interaction == "XY":
+            raise NotImplementedError("dist_grad is not available in the XY mode: its exchange terms enter the native solver as "
+                                      "constant two-qubit blocks (pulser_diff_amd/hamiltonian.py:_xy_pair_terms).")
         if dist_grad:
             for k, v in self._hamiltonian._dist_dict.items():  # backend.py:456-460
                 if v.requires_grad:
@@ -402,6 +407,43 @@ class TorchEmulator:
         n_measures = self.config.runs * self.config.samples_per_run
         results = [SampledResult(tuple(ham._qdict), self._meas_basis, total_count[t]) for t in range(n_t)]
         return NoisyResults(results, ham._size, ham.basis_name, self._eval_times_array, n_measures)
+
+    def refresh_from_sequence(self, sequence, with_modulation: bool = False) -> bool:
+        """Persistent problem object for training loops: the reference builds a NEW emulator — and
+        with it every sparse operator — on each epoch (``pulser_diff/model.py:405-414``).  Here a built sequence with the SAME
+        structure as the one this emulator was made from (same channels, same total duration, same register ids) only
+        re-samples the pulses and rebuilds the coefficient tables / pair interactions in place (torch ops, so the autograd
+        history to the new parameter values is kept); evaluation times, initial state, configuration and the basis objects
+        stay.  Returns False — and changes nothing — when the structure differs; the caller then builds a new emulator."""
+        native = isinstance(sequence, pulses.Sequence)
+        sampler = pulses.sample if native else pulser_adapter.sample_pulser_sequence
+        if sequence.is_parametrized() or sequence.is_register_mappable():
+            raise ValueError("The provided sequence needs to be built to be simulated.")
+        sampled = pulser_adapter.adapt_samples(sampler(sequence, modulation=with_modulation,
+                                                       extended_duration=sequence.get_duration(include_fall_time=with_modulation)))
+        register = pulser_adapter.adapt_register(sequence.register)
+        old = self.samples_obj
+        if (sampled.max_duration != self._tot_duration or tuple(register.qubit_ids) != tuple(self._register.qubit_ids)
+                or list(sampled.channels) != list(old.channels) or sampled.used_bases != old.used_bases
+                or sampled._slm_mask != old._slm_mask
+                or any(sampled._ch_objs[c] != old._ch_objs[c] for c in sampled.channels)):
+            return False
+        samples_list = []
+        for ch, ch_samples in sampled.channel_samples.items():
+            if sampled._ch_objs[ch].addressing == "Local":
+                samples_list.append(ch_samples)
+            else:  # backend.py:102-112
+                samples_list.append(replace(ch_samples, slots=[replace(slot, targets=frozenset(register.qubit_ids))
+                                                               for slot in ch_samples.slots]))
+        self._register = register
+        self.samples_obj = replace(sampled, samples_list=samples_list).extend_duration(self._tot_duration + 1)
+        ham = self._hamiltonian
+        ham.samples_obj = self.samples_obj
+        ham._qdict = {k: (v if isinstance(v, Tensor) else torch.as_tensor(v)).to(torch.float64) for k, v in register.qubits.items()}
+        ham._dist_dict = {}
+        ham._construct_hamiltonian()
+        self.dist_dict = {}
+        return True
 
     @classmethod
     def from_sequence(cls, sequence, sampling_rate: float = 1.0, config: Optional[SimConfig] = None,

@@ -107,13 +107,25 @@ class Hamiltonian:
         self._construct_hamiltonian()
 
     def _build_basis_and_op_matrices(self) -> None:
-        """hamiltonian.py:288-318, ground-rydberg branch."""
-        if self._interaction == "XY" or "digital" in self.samples_obj.used_bases:
-            raise NotImplementedError("Only the ground-rydberg basis is supported by the MI355X-native backend.")
-        self.basis_name = "ground-rydberg"
+        """hamiltonian.py:288-318.  The three two-level bases share one structure — a lowering operator |1><0| (sigma_gr /
+        sigma_hg / sigma_du) driven by 0.5*amp*exp(-i*phase) and a projector |0><0| (sigma_rr / sigma_gg / sigma_uu) weighted by
+        -0.5*det (hamiltonian.py:410-416) — so all of them run on the same kernels; they differ in the interaction term only."""
+        if self._interaction == "XY":
+            self.basis_name = "XY"
+            basis = ["u", "d"]
+            projectors = ["uu", "du", "ud", "dd"]
+        elif "digital" not in self.samples_obj.used_bases:
+            self.basis_name = "ground-rydberg"
+            basis = ["r", "g"]
+            projectors = ["gr", "rr", "gg"]
+        elif "ground-rydberg" not in self.samples_obj.used_bases:
+            self.basis_name = "digital"
+            basis = ["g", "h"]
+            projectors = ["hg", "hh", "gg"]
+        else:
+            raise NotImplementedError("The three-level 'all' basis (ground-rydberg and digital channels in one sequence, "
+                                      "hamiltonian.py:306-310) is not supported by the MI355X-native backend.")
         self.dim = 2
-        basis = ["r", "g"]
-        projectors = ["gr", "rr", "gg"]
         self.basis = {b: basis_state(self.dim, i) for i, b in enumerate(basis)}
         self.op_matrix = {"I": torch.eye(self.dim).to_sparse()}
         for proj in projectors:
@@ -239,6 +251,7 @@ class Hamiltonian:
         for q1, q2 in itertools.combinations(self._qdict.keys(), r=2):
             self._dist_dict[f"{q1}-{q2}"] = torch.linalg.norm(self._qdict[q1] - self._qdict[q2])
         self._rebuild_u_pairs()
+        self.pair_terms = self._xy_pair_terms() if self._interaction == "XY" else ()
 
         amp_terms: list[tuple[Tensor, int]] = []
         det_terms: list[tuple[Tensor, int]] = []
@@ -262,8 +275,8 @@ class Hamiltonian:
             for basis in self.samples[addr]:
                 if not self.samples[addr][basis]:
                     continue
-                if basis != "ground-rydberg":
-                    raise NotImplementedError("Only the ground-rydberg basis is supported.")
+                if basis != self.basis_name:
+                    raise NotImplementedError(f"Samples in the {basis!r} basis next to the {self.basis_name!r} basis are not supported.")
                 if addr == "Global":
                     add_terms(self.samples[addr][basis], all_mask)
                 else:
@@ -284,15 +297,55 @@ class Hamiltonian:
         self._hamiltonian = self.build_ham_tensor()
 
     def _rebuild_u_pairs(self) -> None:
-        """U_ij = C6 / r_ij^6 from the stored distance tensors (hamiltonian.py:341-344)."""
-        us = [self._device.interaction_coeff / d**6 for d in self._dist_dict.values()]
-        self._u_pairs_host = torch.stack(us) if us else torch.zeros(0, dtype=RD)
+        """U_ij = C6 / r_ij^6 from the stored distance tensors (hamiltonian.py:341-344).  The digital basis has no
+        interaction term (hamiltonian.py:460) and the XY interaction is not diagonal (pair terms, below): zeros there."""
+        if self.basis_name != "ground-rydberg":
+            self._u_pairs_host = torch.zeros(len(self._dist_dict), dtype=RD)
+        else:
+            us = [self._device.interaction_coeff / d**6 for d in self._dist_dict.values()]
+            self._u_pairs_host = torch.stack(us) if us else torch.zeros(0, dtype=RD)
         self.u_pairs = self._u_pairs_host.to(self._compute_device)
+
+    # XY_HERMITIAN = False reproduces the reference LITERALLY: it assembles the interaction as `2 * int_mat` with
+    # int_mat = sum_{q1<q2} U sigma_ud(q1) sigma_du(q2) (hamiltonian.py:346-366, :536) — the `+ adjoint()` that the amplitude
+    # and detuning terms get (:540, :544) is missing for the interaction term, which is harmless for the diagonal van der
+    # Waals operator but leaves the XY exchange ONE-DIRECTIONAL (|d u> -> |u d> only): a non-Hermitian generator.  The
+    # upstream QutipEmulator adds the Hermitian conjugate.  Set it to True for the physical exchange U (s+s- + s-s+).
+    XY_HERMITIAN = False
+    MAX_XY_QUBITS = 8  # the library takes up to RYDIFF_MAX_PAIR_TERMS = 28 dense two-qubit terms
+
+    def _xy_pair_terms(self) -> tuple:
+        """hamiltonian.py:346-366: U = 0.5 * C3 * (1 - 3 cos^2 theta) / r^3 per pair, theta between the inter-atomic axis and
+        the magnetic field; the generator carries 2 U (hamiltonian.py:536).  Returned as dense 4x4 blocks (index
+        2*bit(q1) + bit(q2), u = 0, d = 1) for the library's pair terms; constants: no gradient w.r.t. the coordinates."""
+        if self.samples_obj._slm_mask.end > 0:
+            raise NotImplementedError("XY interaction with an SLM mask: the reference builds a time-dependent interaction "
+                                      "term there (hamiltonian.py:462-482) that its own build_ham_tensor cannot take.")
+        if self._size > self.MAX_XY_QUBITS:
+            raise NotImplementedError(f"The XY mode is limited to {self.MAX_XY_QUBITS} qubits (one dense pair term per pair).")
+        terms = []
+        ids = list(self._qdict)
+        field = self.samples_obj._magnetic_field
+        for a, b in itertools.combinations(range(self._size), 2):
+            q1, q2 = ids[a], ids[b]
+            diff = self._qdict[q1] - self._qdict[q2]
+            dist = torch.linalg.norm(diff)
+            mag = torch.as_tensor(field, dtype=RD)[: len(diff)]
+            mag_norm = torch.linalg.norm(mag)
+            cosine = 0.0 if mag_norm < 1e-8 else float(torch.dot(diff, mag) / (dist * mag_norm))
+            j = float(self._device.interaction_coeff_xy) * (1 - 3 * cosine**2) / float(dist) ** 3  # = 2 U
+            block = torch.zeros(4, 4, dtype=CD)
+            block[1, 2] = j  # |u_q1 d_q2><d_q1 u_q2|: own = (u, d) = 1, source = (d, u) = 2
+            if self.XY_HERMITIAN:
+                block[2, 1] = j
+            if j != 0.0:
+                terms.append((a, b, block.numpy()))
+        return tuple(terms)
 
     def problem_spec(self, solver: SolverType = SolverType.KRYLOV_SE, tol: float = 0.0,
                      store_states: bool = True) -> ProblemSpec:
         return ProblemSpec(self._size, self.dt, self.n_samples, self.amp_masks, self.det_masks, solver=solver, tol=tol,
-                           store_states=store_states)
+                           store_states=store_states, pair_terms=tuple(getattr(self, "pair_terms", ())))
 
     # ------------------------------------------------------------------------------------------------------
     def _interp(self, coeff: Tensor, t: Tensor) -> Tensor:
@@ -332,6 +385,18 @@ class Hamiltonian:
                         rows += [g_rows, g_rows ^ m]
                         cols += [g_rows ^ m, g_rows]
                         vals += [c * torch.ones(len(g_rows), dtype=CD), torch.conj(c) * torch.ones(len(g_rows), dtype=CD)]
+            for qa, qb, block in getattr(self, "pair_terms", ()):  # XY exchange (dense two-qubit blocks)
+                ma, mb = 1 << (n - 1 - qa), 1 << (n - 1 - qb)
+                for own in range(4):
+                    for src in range(4):
+                        c = complex(block[own][src])
+                        if c == 0:
+                            continue
+                        r_ = x[(((x & ma) != 0).long() * 2 + ((x & mb) != 0).long()) == own]
+                        c_ = (r_ & ~(ma | mb)) | (ma if src & 2 else 0) | (mb if src & 1 else 0)
+                        rows.append(r_)
+                        cols.append(c_)
+                        vals.append(c * torch.ones(len(r_), dtype=CD))
             return torch.sparse_coo_tensor(torch.stack([torch.cat(rows), torch.cat(cols)]), torch.cat(vals),
                                            (dim, dim)).coalesce()
 

@@ -148,13 +148,18 @@ class QuantumModel(Module):
             self.built_seq = self._seq.build(**values) if self._seq.is_parametrized() else self._seq
 
     def _run(self, observables=None) -> tuple[Tensor, SimulationResults]:
-        """model.py:405-414."""
-        self._sim = TorchEmulator.from_sequence(self.built_seq, sampling_rate=self.sampling_rate,
-                                                compute_device=self.compute_device)
-        if self.initial_state is not None:
-            self._sim.set_initial_state(self.initial_state)
-        if self.noise_config is not None:
-            self._sim.set_config(self.noise_config)
+        """model.py:405-414 — but the emulator PERSISTS between epochs: while the built sequence keeps its structure (the usual
+        case: only parameter values move) its coefficient tables are refreshed in place instead of building a new emulator."""
+        sim = getattr(self, "_sim", None)
+        if sim is None or not sim.refresh_from_sequence(self.built_seq):
+            self._sim = TorchEmulator.from_sequence(self.built_seq, sampling_rate=self.sampling_rate,
+                                                    compute_device=self.compute_device)
+            if self.initial_state is not None:
+                self._sim.set_initial_state(self.initial_state)
+            if self.noise_config is not None:
+                self._sim.set_config(self.noise_config)
+        elif self.noise_config is not None and any(n in self.noise_config.noise for n in ("doppler", "amplitude", "SPAM")):
+            self._sim.set_config(self.noise_config)  # stochastic noise: a fresh realisation per epoch, as a new emulator would draw
         results = self._sim.run(time_grad=self.time_grad, dist_grad=self.dist_grad, solver=self.solver,
                                 observables=observables, **self.options)
         return self._sim.evaluation_times, results

@@ -77,8 +77,11 @@ class Device:
 
     name: str = "MockDevice"
     interaction_coeff: float = 5420158.53  # C6/hbar for Rydberg level 70, rad/us*um^6 (pinned by KA-1..KA-5)
-    supported_bases: frozenset = frozenset({"ground-rydberg"})
-    supports_slm_mask: bool = False
+    # C3/hbar of the XY (microwave) mode, rad/us*um^3 (hamiltonian.py:365; pulser's MockDevice value as recalled: NOT pinned by
+    # any stored output of the reference, whose tests and notebooks never run the XY mode)
+    interaction_coeff_xy: float = 3700.0
+    supported_bases: frozenset = frozenset({"ground-rydberg", "digital", "XY"})
+    supports_slm_mask: bool = True
     max_atom_num: Optional[int] = None
 
     def validate_register(self, register: "Register") -> None:
@@ -275,6 +278,20 @@ class Pulse:
     def ConstantAmplitude(cls, amplitude, detuning: Waveform, phase, post_phase_shift=0.0) -> "Pulse":
         return cls(ConstantWaveform(detuning.duration, amplitude), detuning, phase, post_phase_shift)
 
+    @classmethod
+    def ArbitraryPhase(cls, amplitude: Waveform, phase: Waveform, post_phase_shift=0.0) -> "Pulse":
+        """Phase-modulated pulse (pulser ``Pulse.ArbitraryPhase``, restated from its published behaviour — NOT pinned by any
+        stored output of the reference): the time-dependent phase phi(t) becomes the detuning -dphi/dt (per-ns samples in rad, so
+        x 1e3 for rad/us; the first difference is used for the first two samples) on top of the constant phase phi(0)."""
+        if not isinstance(phase, Waveform):
+            raise TypeError("'phase' must be a waveform")
+        if phase.duration != amplitude.duration:
+            raise ValueError("The duration of phase and amplitude waveforms must match.")
+        ph = phase.samples
+        d = -(ph[1:] - ph[:-1]) * 1e3
+        det = torch.cat([d[:1], d]) if d.numel() else torch.zeros_like(ph)
+        return cls(amplitude, CustomWaveform(det), ph[0], post_phase_shift)
+
 
 # ---------------------------------------------------------------------------------------------------------------
 # sampled sequence (the object TorchEmulator is constructed from, backend.py:61-69)
@@ -342,7 +359,8 @@ class SequenceSamples:
 
     @property
     def _in_xy(self) -> bool:
-        return False
+        """pulser SequenceSamples._in_xy: the sequence drives the XY (microwave) basis."""
+        return any(info.basis == "XY" for info in self._ch_objs.values())
 
     def extend_duration(self, new_duration: int) -> "SequenceSamples":
         return replace(self, samples_list=[s.extend_duration(new_duration) for s in self.samples_list])
@@ -355,16 +373,33 @@ class SequenceSamples:
             info = self._ch_objs[ch]
             cs = cs.extend_duration(d)
             if info.addressing == "Global" and not all_local:
+                # SLM mask (pulser semantics, restated): until the mask ends the global pulse acts on the UNMASKED qubits only,
+                # i.e. it is a set of local pulses there; from the mask's end on it is the plain global pulse
+                start_t = min(self._slm_mask.end, d) if self._slm_mask.targets else 0
                 g = out["Global"].setdefault(info.basis, {q: torch.zeros(d, dtype=RD) for q in ("amp", "det", "phase")})
+                keep = torch.ones(d, dtype=RD)
+                keep[:start_t] = 0.0
                 for q in ("amp", "det", "phase"):
-                    g[q] = g[q] + getattr(cs, q)
+                    g[q] = g[q] + getattr(cs, q) * keep
+                if start_t > 0:
+                    loc = out["Local"].setdefault(info.basis, {})
+                    for slot in cs.slots:
+                        for qid in sorted(slot.targets - self._slm_mask.targets, key=str):
+                            e = loc.setdefault(qid, {q: torch.zeros(d, dtype=RD) for q in ("amp", "det", "phase")})
+                            mask = torch.zeros(d, dtype=RD)
+                            mask[slot.ti:min(slot.tf, start_t)] = 1.0
+                            for q in ("amp", "det", "phase"):
+                                e[q] = e[q] + getattr(cs, q) * mask
             else:
                 loc = out["Local"].setdefault(info.basis, {})
                 for slot in cs.slots:
                     for qid in sorted(slot.targets, key=str):  # deterministic order
                         e = loc.setdefault(qid, {q: torch.zeros(d, dtype=RD) for q in ("amp", "det", "phase")})
                         mask = torch.zeros(d, dtype=RD)
-                        mask[slot.ti:slot.tf] = 1.0
+                        ti = slot.ti
+                        if info.addressing == "Global" and qid in self._slm_mask.targets:
+                            ti = max(ti, self._slm_mask.end)  # masked qubits see a global pulse only after the mask's end
+                        mask[ti:slot.tf] = 1.0
                         for q in ("amp", "det", "phase"):
                             e[q] = e[q] + getattr(cs, q) * mask
         return out
@@ -373,7 +408,9 @@ class SequenceSamples:
 class Sequence:
     """Pulse schedule on declared channels.  Channels run on independent timelines; `delay` inserts idle time."""
 
-    _CHANNELS = {"rydberg_global": ChannelInfo("Global"), "rydberg_local": ChannelInfo("Local")}
+    _CHANNELS = {"rydberg_global": ChannelInfo("Global"), "rydberg_local": ChannelInfo("Local"),
+                 "raman_global": ChannelInfo("Global", "digital"), "raman_local": ChannelInfo("Local", "digital"),
+                 "mw_global": ChannelInfo("Global", "XY")}
 
     def __init__(self, register: Register, device: Device = MockDevice):
         device.validate_register(register)
@@ -383,6 +420,8 @@ class Sequence:
         self._schedule: dict[str, list] = {}
         self._targets: dict[str, frozenset] = {}
         self._slm_mask_targets: set = set()
+        self._slm_mask_time: list = []          # [ti, tf] of the first pulse on a global channel after config_slm_mask
+        self._magnetic_field: Optional[Tensor] = None
         self._variables: dict[str, Variable] = {}
 
     @property
@@ -405,6 +444,9 @@ class Sequence:
         out = Sequence(self.register, self.device)
         out._channels = dict(self._channels)
         out._targets = dict(self._targets)
+        out._slm_mask_targets = set(self._slm_mask_targets)
+        out._slm_mask_time = list(self._slm_mask_time)
+        out._magnetic_field = self._magnetic_field
         out._schedule = {ch: [(kind, obj.build(values) if kind == "pulse" else obj, tg) for kind, obj, tg in items]
                          for ch, items in self._schedule.items()}
         return out
@@ -420,8 +462,12 @@ class Sequence:
         if name in self._channels:
             raise ValueError("The given name is already in use.")
         if channel_id not in self._CHANNELS:
-            raise ValueError(f"Channel {channel_id!r} is not supported by this backend (ground-rydberg only).")
+            raise ValueError(f"Channel {channel_id!r} is not supported by this backend.")
         info = self._CHANNELS[channel_id]
+        if self._channels and (info.basis == "XY") != any(c.basis == "XY" for c in self._channels.values()):
+            raise ValueError("XY (microwave) channels cannot be combined with channels of the other bases.")
+        if info.basis == "XY" and self._magnetic_field is None:
+            self._magnetic_field = torch.tensor([0.0, 0.0, 30.0], dtype=RD)  # pulser's default field (along z)
         self._channels[name] = info
         self._schedule[name] = []
         if info.addressing == "Global":
@@ -444,7 +490,26 @@ class Sequence:
             raise ValueError("Use the name of a declared channel.")
         if not self._targets[channel]:
             raise ValueError("Local channel has no target: call `target` first.")
+        if self._slm_mask_targets and not self._slm_mask_time and self._channels[channel].addressing == "Global":
+            ti = self.get_duration(channel)
+            if not is_param(pulse.duration):
+                self._slm_mask_time = [ti, ti + int(pulse.duration)]  # the mask shields its targets from THIS pulse
         self._schedule[channel].append(("pulse", pulse, self._targets[channel]))
+
+    def config_slm_mask(self, qubits) -> None:
+        """pulser Sequence.config_slm_mask: the targets do not see the first pulse of a global channel."""
+        q = set(qubits)
+        if not q <= set(self.register.qubit_ids):
+            raise ValueError("SLM mask targets must exist in the register.")
+        if self._slm_mask_targets:
+            raise ValueError("SLM mask can be configured only once.")
+        if not self.device.supports_slm_mask:
+            raise ValueError("The device does not have an SLM mask.")
+        self._slm_mask_targets = q
+
+    def set_magnetic_field(self, bx: float = 0.0, by: float = 0.0, bz: float = 30.0) -> None:
+        """pulser Sequence.set_magnetic_field (XY mode; hamiltonian.py:355-364 reads it for the angular factor)."""
+        self._magnetic_field = torch.tensor([bx, by, bz], dtype=RD)
 
     def delay(self, duration: int, channel: str) -> None:
         self._schedule[channel].append(("delay", int(duration), self._targets[channel]))
@@ -463,8 +528,8 @@ class Sequence:
 
 def sample(sequence: Sequence, modulation: bool = False, extended_duration: Optional[int] = None) -> SequenceSamples:
     """pulser.sampler.sample restated for the supported subset (backend.py:701-705)."""
-    if modulation:
-        raise NotImplementedError("Output-modulated sampling is not supported by this backend.")
+    # modulation=True: pulser modulates the channels that declare a modulation bandwidth; the channels of this stand-in device
+    # (MockDevice) declare none, for which the programmed input IS the output — nothing to do
     channels, samples_list = [], []
     for name, items in sequence._schedule.items():
         amps, dets, phases, slots = [], [], [], []
@@ -486,6 +551,8 @@ def sample(sequence: Sequence, modulation: bool = False, extended_duration: Opti
                             torch.cat(phases) if phases else empty, slots)
         channels.append(name)
         samples_list.append(cs)
-    out = SequenceSamples(channels, samples_list, dict(sequence._channels))
+    mask = _SlmMask(frozenset(sequence._slm_mask_targets), sequence._slm_mask_time[1]) if (
+        sequence._slm_mask_targets and sequence._slm_mask_time) else _SlmMask()
+    out = SequenceSamples(channels, samples_list, dict(sequence._channels), _slm_mask=mask, _magnetic_field=sequence._magnetic_field)
     total = max(out.max_duration, extended_duration or 0)
     return out.extend_duration(total)

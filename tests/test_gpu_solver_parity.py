@@ -294,8 +294,8 @@ def test_xcd_placement_changes_speed_only(cuda_device, n_qubits, batch, store):
         out[variant] = [states.detach().cpu().numpy(), expect.detach().cpu().numpy(), amp.grad.cpu().numpy(), det.grad.cpu().numpy(),
                         u.grad.cpu().numpy()]
     for name, a, b in zip(("states", "expect", "amp", "det", "u"), out[2], out[10]):
-        if a.size:
-            assert rel_err(b, a) < 1e-12, name
+        if a.size:  # gradients: the replica slot of a tile's atomics differs between the two grids, i.e. the summation order
+            assert rel_err(b, a) < (1e-12 if name in ("states", "expect") else 1e-10), name
 
 
 def test_chained_tile_kernels_against_matrix_free_oracle(cuda_device):
