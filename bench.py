@@ -54,7 +54,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="auto", choices=["auto", "c1", "c2", "c3", "c4", "c5", "tiny"])
     ap.add_argument("--batch", type=int, default=0, help="c4: parameter sets of the whole job (default 256); c3/tiny: per rank")
-    ap.add_argument("--chunk", type=int, default=C4_CHUNK, help="c4: trajectories evolved per solver call")
+    ap.add_argument("--chunk", type=int, default=0, help="c4: trajectories evolved per solver call (0: the largest power of two <= 32 whose full tape fits in HBM)")
     ap.add_argument("--time-steps", type=int, default=0, help="override the number of time steps (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c4-reference", action="store_true", help="N=1 default run: skip the secondary single-GPU c4 figure")
@@ -248,7 +248,16 @@ def run_trajectories(args, workload: str, rank: int, world: int, device, barrier
     tsave = torch.arange(T + 1, dtype=torch.float64) / 1000.0
     zd = z_diag(n_qubits, device)
     all_mask = (1 << n_qubits) - 1
-    chunk = max(1, min(args.chunk if workload == "c4" else mine, mine)) if mine else 1
+    chunk = max(1, min((args.chunk or C4_CHUNK) if workload == "c4" else mine, mine)) if mine else 1
+    if workload == "c4" and args.chunk == 0 and mine and not STANDIN:
+        # automatic: the largest power-of-two chunk (<= 32) whose FULL tape — every factor output of every trajectory, so that
+        # the adjoint sweep recomputes nothing — fits in 70 % of the free HBM (ten factor passes per step as an upper estimate)
+        free, _tot = torch.cuda.mem_get_info(device)
+        per_traj = (T * 11 + 1) * 16.0 * dim
+        chunk = 32
+        while chunk > 1 and chunk * per_traj > 0.7 * free:
+            chunk //= 2
+        chunk = min(chunk, mine)
 
     def make_spec():
         return ProblemSpec(n_qubits, 0.001, T + 1, (all_mask,), (all_mask,), solver=SolverType.KRYLOV_SE,
@@ -281,11 +290,12 @@ def run_trajectories(args, workload: str, rank: int, world: int, device, barrier
                 amp, det = tables_from_params(omega[a:b], delta[a:b], seg_len)
                 if not grad:
                     amp, det = amp.detach(), det.detach()
-            _, expect = evolve(amp, det, u_pairs, tsave, psi0_for(b - a), sp, zd[None])
+            states, expect = evolve(amp, det, u_pairs, tsave, psi0_for(b - a), sp, zd[None])
             loss = expect[0, -1, :].sum()
             if grad:
                 loss.backward()
             loss_sum += loss.detach()
+            del states, expect, loss, amp, det  # releases this chunk's tape workspace before the next chunk plans its own
         return loss_sum
 
     for _ in range(args.warmup):
@@ -385,7 +395,7 @@ def run_trajectories(args, workload: str, rank: int, world: int, device, barrier
         times = []
         for _ in range(2):
             amp_b, det_b = tables_from_params(om, de, seg_len)
-            _, ex = evolve(amp_b, det_b, u_pairs, tsave, psi_f, spec_b, zd[None])
+            st_b, ex = evolve(amp_b, det_b, u_pairs, tsave, psi_f, spec_b, zd[None])
             l = ex[0, -1, :].sum()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -396,7 +406,7 @@ def run_trajectories(args, workload: str, rank: int, world: int, device, barrier
             times.append(e0.elapsed_time(e1))
             om.grad = None
             de.grad = None
-            del ex, l, amp_b, det_b  # frees the run's tape workspace before the next run plans its own (two full tapes do not fit)
+            del st_b, ex, l, amp_b, det_b  # frees the run's tape workspace (every output holds the autograd node that owns it)
         bwd_ms = times[-1]
         tape = spec_b.options["_last_stats"].get("tape")
         n_launch = total_factors * (1 if tape == "full" else 2)  # one state per save point: recompute pass + adjoint pass per factor
@@ -454,11 +464,13 @@ def c4_reference(args) -> dict:
         torch.cuda.synchronize()
 
     warm = argparse.Namespace(**vars(sub))
-    warm.batch = C4_CHUNK  # one chunk of 32 to page the kernels in
+    warm.batch = 16  # one small chunk to page the kernels in
     run_trajectories_quiet(warm, device, barrier)
     r = run_trajectories_quiet(sub, device, barrier)
     return {"value": r["value"], "unit": "time-steps/s", "ms_per_step": r["ms_per_step"], "workload": r["config"]["workload"],
-            "kernel_family": r["config"]["kernel_family"], "tape": r["config"]["tape"]}
+            "trajectories_per_solver_call": r["config"]["trajectories_per_solver_call"],
+            "kernel_family": r["config"]["kernel_family"], "tape": r["config"]["tape"],
+            "forward_only_time_steps_per_s": r.get("forward_only_time_steps_per_s")}
 
 
 def run_trajectories_quiet(args, device, barrier) -> dict:
