@@ -427,10 +427,11 @@ def run_distributed_native(prob: ShardedProblem, psi0_local: Tensor, tsave, grou
                     state["staged"] = [torch.empty_like(x) for _ in range(g)]
                 bufs = state["staged"] if via_host else recv
                 reqs = []
+                xr = torch.view_as_real(x)  # (the transports carry real dtypes)
                 for k in range(g):  # hypercube neighbours: all links in flight together
                     partner = rank ^ (1 << k)
-                    reqs.append(dist.P2POp(dist.isend, x, partner, group))
-                    reqs.append(dist.P2POp(dist.irecv, bufs[k], partner, group))
+                    reqs.append(dist.P2POp(dist.isend, xr, partner, group))
+                    reqs.append(dist.P2POp(dist.irecv, torch.view_as_real(bufs[k]), partner, group))
                 state["works"] = dist.batch_isend_irecv(reqs)
             else:
                 for w in state["works"]:
