@@ -23,7 +23,7 @@ for case in range(n_cases):
     n = int(rng.integers(min_q, max_q + 1))
     ns = int(rng.integers(6, 14))
     dt = float(rng.choice([0.001, 0.002, 0.004]))
-    batch = int(rng.choice([1, 1, 2, 3])) if n <= 14 else 1
+    batch = int(rng.choice([1, 1, 2, 3, 9])) if n <= 14 else (int(rng.choice([1, 1, 9])) if n <= 16 else 1)
     per_traj = bool(rng.integers(0, 2)) and batch > 1
     solver = SolverType.DP5_SE if rng.random() < 0.35 else SolverType.KRYLOV_SE
     cplx = rng.random() < 0.6
@@ -52,7 +52,7 @@ for case in range(n_cases):
         amp = amp.real.contiguous()
     tape = str(rng.choice(["auto", "steps", "full"]))
     out = {}
-    variants = (1, 0) + ((int(rng.choice([2, 4])),) if n >= 13 else ())  # from 13 qubits also the chained tiles FORCED: auto routes small single trajectories to the direct kernels
+    variants = (1, 0) + ((int(rng.choice([2, 4, 10])),) if n >= 13 else ())  # 10: trajectory-per-XCD placement  # from 13 qubits also the chained tiles FORCED: auto routes small single trajectories to the direct kernels
     for variant in variants:
         _native.set_kernel_variant(variant)
         spec = ProblemSpec(n, dt, ns, am, dm, solver=solver, store_states=store, tape=tape)
