@@ -235,6 +235,11 @@ int rydiff_design_polynomial(double rho, double tol, int max_degree, int* degree
 const char* rydiff_last_error(void);
 const char* rydiff_version(void);
 
+/* sizeof(RydProblem) / sizeof(RydPlanInfo) as this library was compiled: lets a foreign-language binding (ctypes, cgo, JNI)
+ * assert that its mirror of the two structs has the same layout before it passes one in. */
+size_t rydiff_sizeof_problem(void);
+size_t rydiff_sizeof_plan_info(void);
+
 #ifdef __cplusplus
 }
 #endif

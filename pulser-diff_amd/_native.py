@@ -92,6 +92,8 @@ EXPORTS = (
     "rydiff_design_polynomial",
     "rydiff_last_error",
     "rydiff_version",
+    "rydiff_sizeof_problem",
+    "rydiff_sizeof_plan_info",
 )
 
 _lib = None
@@ -132,6 +134,10 @@ def lib() -> ctypes.CDLL:
     L.rydiff_design_polynomial.restype = i32
     L.rydiff_last_error.restype = ctypes.c_char_p
     L.rydiff_version.restype = ctypes.c_char_p
+    L.rydiff_sizeof_problem.restype = ctypes.c_size_t
+    L.rydiff_sizeof_plan_info.restype = ctypes.c_size_t
+    if (L.rydiff_sizeof_problem(), L.rydiff_sizeof_plan_info()) != (ctypes.sizeof(RydProblem), ctypes.sizeof(RydPlanInfo)):
+        raise RuntimeError(f"{_LIB_PATH} was built from another include/rydiff.h than this binding mirrors (struct sizes differ): rebuild it")
     _lib = L
     return L
 

@@ -1909,6 +1909,8 @@ extern "C" {
 
 const char* rydiff_last_error(void) { return g_last_error.c_str(); }
 const char* rydiff_version(void) { return "rydiff 0.2 (gfx950)"; }
+size_t rydiff_sizeof_problem(void) { return sizeof(RydProblem); }
+size_t rydiff_sizeof_plan_info(void) { return sizeof(RydPlanInfo); }
 
 #ifdef RYDIFF_TIMELINE
 int rydiff_debug_timeline(unsigned long long* host_buf, int n_entries) {  // tuning builds only
