@@ -10,7 +10,10 @@ What changes for a user switching over:
   * stochastic noise (``SimConfig(noise=("doppler", "amplitude", "SPAM"))``) runs all realisations as ONE batch of
     trajectories and returns ``NoisyResults``; collapse-operator noise (dephasing, relaxation, depolarizing, eff_noise) and
     ``SolverType.DP5_ME`` run the master equation on a doubled register (``lindblad.py``) and return density matrices;
-    the digital / XY bases, leakage and SLM masks raise ``NotImplementedError``.
+  * the digital basis, the XY mode (up to 8 qubits; its exchange exactly as the reference assembles it, see
+    ``hamiltonian.Hamiltonian.XY_HERMITIAN``) and SLM masks run on the same kernels; the three-level "all" basis (and with it
+    ``with_leakage``, which the reference only forwards to Pulser's NoiseModel) raises ``NotImplementedError``;
+  * a training loop keeps ONE emulator and calls ``refresh_from_sequence`` per epoch (``model.QuantumModel`` does).
 """
 from __future__ import annotations
 
