@@ -262,9 +262,10 @@ def test_chained_tile_kernels_match_direct_kernels(cuda_device, n_qubits, local,
     assert rel_err(got["states"].cpu().numpy(), ref["states"].cpu().numpy()) < 1e-12
     assert np.abs((got["expect"] - ref["expect"]).cpu().numpy()).max() < 1e-10
     # gradients: sums over up to 2^25 contributions that cancel by several orders (a smooth pulse barely moves <sum Z>); the
-    # summation ORDER differs between the families (tile reductions + replicated atomics), hence 1e-9 from 23 qubits on
+    # summation ORDER differs between the families and from run to run (tile reductions + replicated atomics), hence 1e-9 from
+    # 21 qubits on (observed up to 2.3e-10 there)
     for key in ("amp", "det", "u"):
-        assert rel_err(got[key].cpu().numpy(), ref[key].cpu().numpy()) < (1e-10 if n_qubits < 23 else 1e-9), key
+        assert rel_err(got[key].cpu().numpy(), ref[key].cpu().numpy()) < (1e-10 if n_qubits < 21 else 1e-9), key
 
 
 @pytest.mark.parametrize("n_qubits,batch,store", [(13, 11, True), (14, 19, False), (16, 9, False), (17, 3, True)])
