@@ -167,13 +167,17 @@ def run_rank(args) -> None:
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
-        device = torch.device("cuda", local_rank)
+        one_gpu = os.environ.get("RYDIFF_BENCH_ONE_GPU") == "1"  # rehearsal on a 1-GPU box: every rank on cuda:0, gloo as transport
+        device = torch.device("cuda", 0 if one_gpu else local_rank)
         torch.cuda.set_device(device)
         if world > 1:
             import datetime
 
             # "nccl" is RCCL on ROCm; a rank that gets stuck fails the job after 5 minutes instead of hanging it
-            dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=300))
+            if one_gpu:
+                dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
+            else:
+                dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=300))
 
     def barrier():
         if world > 1:
