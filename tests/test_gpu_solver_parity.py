@@ -576,3 +576,52 @@ def test_negative_pair_interactions_stay_inside_the_design_interval(cuda_device)
     stats = spec.options["_last_stats"]
     assert stats["spectral"][0] < -float(terms.u_pairs.clamp(max=0).abs().sum()) + 1e-9  # the bound reaches below -sum |U_neg|
     assert rel_err(states.cpu().permute(0, 2, 1).numpy(), ref.numpy()) < 1e-9
+
+
+@pytest.mark.parametrize("n_qubits,variants", [(4, (0, 1)), (8, (0, 1, 9)), (13, (1, 2, 10)), (14, (1, 4))])
+@pytest.mark.parametrize("tape", ["steps", "full"])
+def test_state_cotangents_at_every_save_point(cuda_device, n_qubits, variants, tape):
+    """A loss on the STATES at every evaluation time (grad_states non-zero at every save point, next to expectation
+    cotangents): the cotangents of the intermediate save points are added by the adjoint launch that completes the adjoint
+    state there (fused injection, every kernel family).  Up to 8 qubits against autograd through the oracle's dense map, beyond
+    against the direct kernels."""
+    from pulser_diff_amd.solver import SolverType, evolve
+
+    terms = random_terms(n_qubits, 15, 0.002, seed=900 + n_qubits, local=True)
+    tsave = torch.tensor([0.0, 0.0043, 0.0091, 0.015, 0.0222, 0.026], dtype=torch.float64)
+    gen = torch.Generator().manual_seed(n_qubits)
+    psi0 = torch.randn(2**n_qubits, generator=gen, dtype=torch.complex128)
+    psi0 = psi0 / psi0.norm()
+    cot = torch.randn(len(tsave), 2**n_qubits, generator=gen, dtype=torch.complex128) / 2 ** (n_qubits / 2)
+    w = torch.linspace(-0.4, 0.9, len(tsave), dtype=torch.float64)
+    zd = R.total_magnetization_diag(n_qubits)
+
+    def native(variant):
+        amp, det, u, spec = to_native(terms, cuda_device, SolverType.KRYLOV_SE, store_states=True)
+        spec.kernel_variant, spec.tape = variant, tape
+        for t in (amp, det, u):
+            t.requires_grad_(True)
+        ts = tsave.clone().requires_grad_(True)
+        p0 = psi0[None].to(cuda_device).requires_grad_(True)
+        states, expect = evolve(amp, det, u, ts, p0, spec, zd[None].to(cuda_device))
+        loss = (cot.to(cuda_device).conj() * states[:, 0]).real.sum() + (w.to(cuda_device) * expect[0, :, 0]).sum()
+        loss.backward()
+        return [amp.grad[0].cpu().numpy(), det.grad[0].cpu().numpy(), u.grad.cpu().numpy(), ts.grad.numpy(), p0.grad[0].cpu().numpy()]
+
+    if n_qubits <= 8:
+        o = R.HamTerms(n_qubits, terms.u_pairs.clone().requires_grad_(True), terms.amp_coeff.clone().requires_grad_(True),
+                       terms.det_coeff.clone().requires_grad_(True), terms.dt, terms.n_samples, terms.amp_targets, terms.det_targets)
+        o.extra_amp = [(c.clone().requires_grad_(True), tg) for c, tg in terms.extra_amp]
+        o.extra_det = [(c.clone().requires_grad_(True), tg) for c, tg in terms.extra_det]
+        ts = tsave.clone().requires_grad_(True)
+        p0 = psi0.clone().requires_grad_(True)
+        st = R.krylov_map_dense(o, p0[:, None], ts)[:, :, 0]
+        ((cot.conj() * st).real.sum() + (w * ((st.abs() ** 2) * zd[None]).sum(1)).sum()).backward()
+        ref = [torch.stack([c.grad for c, _ in o.amp_terms()]).numpy(), torch.stack([c.grad for c, _ in o.det_terms()]).numpy(),
+               o.u_pairs.grad.numpy(), ts.grad.numpy(), p0.grad.numpy()]
+        tol = 1e-8
+    else:
+        ref, variants, tol = native(variants[0]), variants[1:], 1e-10
+    for v in variants:
+        for name, a, b in zip(("amp", "det", "u", "tsave", "psi0"), native(v), ref):
+            assert rel_err(a, b) < tol, (v, name)
