@@ -12,6 +12,13 @@ KA-5 (Adam loss traces = gradient pins).  The reference itself cannot be importe
 (pyqtorch / pulser / pulser_simulation / qutip are absent; ordinary missing modules, no
 permission denial) and its tests hold no static vectors.
 
+The golden vectors of the BASELINE shapes under tests/golden/*.npz are generated FROM this module
+(tests/golden/make_baseline_fixtures.py): the dense map (krylov_map_dense, pinned as above), the matrix-free Lanczos map
+and — for gradients beyond dense H — autograd through the matrix-free Taylor map (krylov_map_matrix_free_torch), the three
+of which are checked against each other in tests/test_oracle_consistency.py.  reference_style_dense_H_t restates the
+reference's operator construction literally for every two-level basis (ground-rydberg, digital, XY), including the XY
+exchange exactly as the reference assembles it.
+
 Third-party owners of arithmetic that are NOT under /root/reference and are restated from
 their published behaviour: ``pyqtorch`` (unpinned, pyproject.toml:31) for sesolve
 (KRYLOV_SE / DP5_SE) and ``pulser-core`` @ fcf980463f47 for waveform sampling
