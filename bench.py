@@ -58,6 +58,7 @@ def parse_args():
     ap.add_argument("--time-steps", type=int, default=0, help="override the number of time steps (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c4-reference", action="store_true", help="N=1 default run: skip the secondary single-GPU c4 figure")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic: quote the committed PMC summary instead of measuring it with child rocprofv3 runs")
     ap.add_argument("--no-c5-leg", action="store_true", help="default run: skip the secondary state-sharded (c5) figure")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (RydProblem.kernel_variant); 0 = automatic")
@@ -391,13 +392,19 @@ def run_trajectories(args, workload: str, rank: int, world: int, device, barrier
     alg_bytes = 32.0 * dim * bsz  # B_mv = 32 * 2^N * B per matrix-free H application
     out["forward_only_time_steps_per_s"] = T * bsz / (fwd_ms * 1e-3)
     per_launch = family in ("chained-tiles", "direct")  # one HBM-level launch per H application
-    kernel_names = {"chained-tiles": "k_chain<12,10,false,false,true> (one factor pass y = gamma*x + beta*H x of the product-form propagator)",
+    kernel_names = {"chained-tiles": "k_chain<12,10,false,false,true,false> (one factor pass y = gamma*x + beta*H x of the product-form propagator)",
                     "direct": "k_factor_direct_global (one factor pass, one amplitude per thread, partners through L2)",
                     "persistent": "k_persist (the whole trajectory in one launch, state in registers + LDS: no HBM traffic per factor)",
                     "lanes": "k_lanes_fwd (the whole trajectory in one launch, one amplitude per lane)"}
     if per_launch:
         achieved = alg_bytes / (launch_us * 1e-6) / 1e9
-        traffic, traffic_src = committed_traffic("fwd") if (workload == "c3" and bsz == 1 and args.variant == 0) else (None, None)
+        traffic, traffic_src = (None, None)
+        if workload == "c3" and bsz == 1 and args.variant == 0:
+            if not args.no_live_traffic and world == 1:
+                torch.cuda.empty_cache()
+                traffic, traffic_src = live_traffic("fwd")
+            if traffic is None:
+                traffic, traffic_src = committed_traffic("fwd")
         out["roofline"] = {"bound": "hbm", "kernel": kernel_names[family], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                            "avg_launch_us": launch_us, "algorithmic_bytes_per_launch": alg_bytes, "launches": total_factors,
@@ -434,8 +441,14 @@ def run_trajectories(args, workload: str, rank: int, world: int, device, barrier
         adj_bytes = 48.0 * dim * bsz  # reads the cotangent and the factor input, writes the cotangent
         a_us = bwd_ms * 1e3 / max(n_launch, 1)
         ach = adj_bytes / (a_us * 1e-6) / 1e9
-        traffic_b, src_b = committed_traffic("bwd") if (workload == "c3" and bsz == 1 and args.variant == 0) else (None, None)
-        out["roofline_adjoint"] = {"bound": "hbm", "kernel": "k_chain<12,10,false,true,true> (adjoint factor pass + gradient contractions)"
+        traffic_b, src_b = (None, None)
+        if workload == "c3" and bsz == 1 and args.variant == 0:
+            if not args.no_live_traffic and world == 1:
+                torch.cuda.empty_cache()
+                traffic_b, src_b = live_traffic("bwd")
+            if traffic_b is None:
+                traffic_b, src_b = committed_traffic("bwd")
+        out["roofline_adjoint"] = {"bound": "hbm", "kernel": "k_chain<12,10,false,true,true,false> (adjoint factor pass + gradient contractions)"
                                    if family == "chained-tiles" else "k_factor_bwd_direct_global",
                                    "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                    "traffic": traffic_b, "traffic_source": src_b, "avg_launch_us": a_us,
@@ -456,6 +469,43 @@ def run_trajectories(args, workload: str, rank: int, world: int, device, barrier
             out["cpu_baseline"] = None
             print(f"bench.py: CPU baseline leg failed: {exc!r}", file=sys.stderr, flush=True)
     return out
+
+
+def live_traffic(which: str):
+    """HBM / fabric bytes per launch of the dominant kernel measured NOW, for this build: two child `rocprofv3 --pmc` runs
+    (FETCH_SIZE and WRITE_SIZE in separate passes, MI355X_MICROARCH.md) of tools/time_forward.py / time_fwdgrad.py on the same
+    20-qubit pass; FETCH_SIZE doubled, WRITE_SIZE exact (both in KiB) as that guide prescribes for 16 B/lane accesses; median
+    over the dispatches of the kernel.  Returns (bytes, description) or (None, None) when the profiler is not usable here."""
+    import csv
+    import glob
+    import shutil
+    import statistics
+    import tempfile
+
+    if shutil.which("rocprofv3") is None:
+        return None, None
+    script = ROOT / "tools" / ("time_forward.py" if which == "fwd" else "time_fwdgrad.py")
+    # k_chain<LT, LGT, CPLX, BWD, FAST, RES>: the instantiations the bench workload runs on
+    want = "k_chain<12, 10, false, false, true, false>" if which == "fwd" else "k_chain<12, 10, false, true, true, false>"
+    out = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            try:
+                subprocess.run(["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", f"{tmp}/{ctr}", "--", "python3", str(script), "20", "10"],
+                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=150, check=True,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            except (subprocess.SubprocessError, OSError):
+                return None, None
+            vals = []
+            for f in glob.glob(f"{tmp}/{ctr}/**/*counter_collection.csv", recursive=True):
+                with open(f) as fh:
+                    vals += [float(r["Counter_Value"]) for r in csv.DictReader(fh)
+                             if r["Counter_Name"] == ctr and want in r["Kernel_Name"]]
+            if not vals:
+                return None, None
+            out[ctr] = statistics.median(vals) * 1024.0
+    return 2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"], ("measured by this run: child rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate) of "
+                                                         f"tools/{script.name} 20 10, FETCH_SIZE x2, median over the kernel's dispatches")
 
 
 def committed_traffic(which: str):
