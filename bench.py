@@ -484,6 +484,8 @@ def live_traffic(which: str):
 
     if shutil.which("rocprofv3") is None:
         return None, None
+    if any(k.startswith(("ROCP", "ROCPROF")) or k == "HSA_TOOLS_LIB" for k in os.environ):
+        return None, None  # this process is itself being profiled: no nested profiler runs (the committed summary is quoted)
     script = ROOT / "tools" / ("time_forward.py" if which == "fwd" else "time_fwdgrad.py")
     # k_chain<LT, LGT, CPLX, BWD, FAST, RES>: the instantiations the bench workload runs on
     want = "k_chain<12, 10, false, false, true, false>" if which == "fwd" else "k_chain<12, 10, false, true, true, false>"
