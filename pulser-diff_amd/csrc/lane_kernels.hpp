@@ -195,6 +195,7 @@ __global__ __launch_bounds__(64) void k_lanes_fwd(PersistArgs a) {
                 q.y += br * pv.y + bi * pv.x;
             }
             v = q;
+            if (a.tape_all && active) a.tape_all[(size_t(f0 + fs + 1) * a.B + b) * a.dim + lane] = v;  // full tape: entry g + 1 = output of factor g
             const int save = __builtin_amdgcn_readlane(cur.save, fs);
             if (save) {
                 if (a.states && active) a.states[(size_t(save) * a.B + b) * a.dim + lane] = v;
@@ -433,6 +434,167 @@ __global__ __launch_bounds__(64) void k_lanes_bwd(PersistBwdArgs a) {
         const double w = weight(inj);
         mu.x += inj.gs.x + w * xend.x;
         mu.y += inj.gs.y + w * xend.y;
+    }
+    if (active) {
+        a.mu_out[boff + lane] = mu;
+        if (a.wtot) unsafeAtomicAdd(a.wtot + lane, wt);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// adjoint sweep on the FULL tape (PersistBwdArgs::tape_full): the forward sweep kept the output of every factor (entry f of
+// the tape = input of factor f, entry n_factors = final state), so nothing is recomputed and the whole reverse pass is ONE
+// descending walk over the factors: the inputs stream in from global memory three factors ahead (they are read exactly once,
+// in reverse order), the state at an interval's end point is simply the input of the factor processed just before.
+// Same contract and arithmetic as k_lanes_bwd.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int LT, bool CPLX, bool FAST, int GLMAX = kPersistGroups>
+__global__ __launch_bounds__(64) void k_lanes_bwd_tape(PersistBwdArgs a) {
+    constexpr int GL = FAST ? 1 : GLMAX;
+    constexpr int NT = 1 << LT;
+    const unsigned lane = threadIdx.x;
+    const bool active = lane < NT;
+    const int b = blockIdx.x;
+    const size_t boff = size_t(b) * a.dim;
+    const size_t sv = size_t(a.B) * a.dim;
+    const unsigned xl = active ? lane : 0u;
+    const double live = active ? 1.0 : 0.0;
+    double cnt[kPersistGroups];
+#pragma unroll
+    for (int g = 0; g < kPersistGroups; ++g) cnt[g] = g < a.gd ? double(a.dcnt[g] - __popc(lane & a.dmask[g])) : 0.0;
+    const double ud = active ? a.udiag[lane] : 0.0;
+    auto entry = [&](int f) -> double2 {
+        const double2 s = a.tape[size_t(f < 0 ? 0 : f) * sv + boff + xl];
+        return make_double2(live * s.x, live * s.y);
+    };
+    const double ob0 = (a.gexp && a.n_obs > 0 && active) ? a.obs[lane] : 0.0;
+    struct Inject {
+        double2 gs;
+        double g0;
+        int flag, k;
+    };
+    auto inject_terms = [&](int k) -> Inject {
+        Inject r{make_double2(0.0, 0.0), 0.0, 0, k};
+        if (k < 0) return r;
+        if (a.gstate) {
+            const double2 s = a.gstate[size_t(k) * sv + boff + xl];
+            r.gs = make_double2(live * s.x, live * s.y);
+        }
+        if (a.gexp) {
+            r.flag = a.gflags ? a.gflags[k] : 1;
+            r.g0 = a.gexp[size_t(k) * a.B + b];
+        }
+        return r;
+    };
+    auto weight = [&](const Inject& r) -> double {
+        if (!a.gexp || r.flag == 0) return 0.0;
+        double wsum = r.g0 * ob0;
+        for (int o = 1; o < a.n_obs; ++o) wsum += a.gexp[(size_t(o) * a.n_tsave + r.k) * a.B + b] * a.obs[size_t(o) * a.dim + xl];
+        return 2.0 * live * wsum;
+    };
+    const int n_save = a.factors[a.n_factors - 1].save_index;  // = T
+    double2 mu = make_double2(0.0, 0.0);
+    double wt = 0.0;
+    // vprev: output of the factor about to be processed (= input of the one processed before); xa, xb, xc: the next inputs
+    double2 vprev = entry(a.n_factors), xa = entry(a.n_factors - 1), xb = entry(a.n_factors - 2), xc = entry(a.n_factors - 3);
+    Inject inj = inject_terms(n_save);
+    double acc_re[kPersistGroups], acc_im[kPersistGroups], acc_det[kPersistGroups], acc_tau = 0.0;
+#pragma unroll
+    for (int g = 0; g < kPersistGroups; ++g) acc_re[g] = acc_im[g] = acc_det[g] = 0.0;
+    LanePairs pairs_adj;  // conjugate transposes of the dense two-qubit blocks
+    pairs_adj.load(a.pair, 1, lane);
+    LaneRecLoader ld{a.factors, a.coef + size_t(b) * a.coef_bstride, a.NC, a.ga, a.gd, a.n_factors, {}};
+    LaneRec cur;
+    int w0 = a.n_factors, w1 = -1;  // window [w0, w1] of factor indices held by lanes 0 .. w1 - w0
+    for (int f = a.n_factors - 1; f >= 0; --f) {
+        if (f < w0) {  // take the kLaneChunk factors ending at f
+            w1 = f;
+            w0 = f - (kLaneChunk - 1) > 0 ? f - (kLaneChunk - 1) : 0;
+            ld.issue_factor(w0);
+            ld.issue_coef(cur);
+        }
+        const int fs = f - w0;
+        const int save = __builtin_amdgcn_readlane(cur.save, fs);
+        if (save) {  // factor f ends the interval of save point `save`: vprev is the state there; add its cotangent
+            const double w = weight(inj);
+            mu.x += inj.gs.x + w * vprev.x;
+            mu.y += inj.gs.y + w * vprev.y;
+            inj = inject_terms(save - 1);  // requested now, consumed at the end of the next interval (or after the loop)
+        }
+        const double2 v = xa;  // input of factor f
+        xa = xb;
+        xb = xc;
+        xc = entry(f - 3);
+        const int stage = __builtin_amdgcn_readlane(cur.stage, fs);
+        const bool stage_end = save != 0 || (fs + 1 <= w1 - w0 ? __builtin_amdgcn_readlane(cur.stage, fs + 1) != stage
+                                                               : a.factors[f + 1].stage != stage);
+        const bool stage_begin = f == 0 || (fs >= 1 ? __builtin_amdgcn_readlane(cur.stage, fs - 1) != stage : a.factors[f - 1].stage != stage);
+        const double gr = bcast_lane(cur.gr, fs), gi = bcast_lane(cur.gi, fs);
+        const double br = bcast_lane(cur.br, fs), bi = bcast_lane(cur.bi, fs);
+        double d = ud;
+#pragma unroll
+        for (int g = 0; g < GL; ++g)
+            if (FAST || g < a.gd) d = fma(bcast_lane(cur.cd[g], fs), cnt[g], d);
+        double2 hm = make_double2(d * mu.x, d * mu.y);  // H mu
+        const double pr = br * mu.x + bi * mu.y, pi = bi * mu.x - br * mu.y;
+        const double rr = pr * v.x - pi * v.y;  // Re(beta conj(mu) x)
+        wt += rr;
+#pragma unroll
+        for (int g = 0; g < GL; ++g)
+            if (FAST || g < a.gd) acc_det[g] = fma(rr, cnt[g], acc_det[g]);
+#pragma unroll
+        for (int g = 0; g < GL; ++g) {
+            if (FAST || g < a.ga) {
+                double2 ts, ds;
+                partner_sums_lanes<LT, true, FAST>(mu, a.amask[g], lane, ts, ds);
+                const double cr = bcast_lane(cur.cr[g], fs), ci = bcast_lane(cur.ci[g], fs);
+                hm.x += cr * ts.x - ci * ds.y;
+                hm.y += cr * ts.y + ci * ds.x;
+                const double z1r = ts.x * v.x + ts.y * v.y, z1i = ts.x * v.y - ts.y * v.x;
+                const double z2r = ds.x * v.x + ds.y * v.y, z2i = ds.x * v.y - ds.y * v.x;
+                acc_re[g] += br * z1r - bi * z1i;
+                acc_im[g] += br * z2i + bi * z2r;
+            }
+        }
+        if (!FAST && pairs_adj.n) {
+            const double2 pv = pairs_adj.apply(mu, lane);
+            hm.x += pv.x;
+            hm.y += pv.y;
+        }
+        if (stage_end && a.want_tau) acc_tau += hm.x * vprev.y - hm.y * vprev.x;  // dL/dtau = Im<M^dagger mu, x_out>, x_out = vprev
+        const double nx = gr * mu.x + gi * mu.y + br * hm.x + bi * hm.y;
+        const double ny = gr * mu.y - gi * mu.x + br * hm.y - bi * hm.x;
+        mu = make_double2(nx, ny);
+        if (stage_begin) {
+            double* rec = a.ge + size_t(b) * a.ge_bstride + size_t(stage) * a.ge_sstride + size_t(b % kGradReplicas) * (a.NC + 1);
+#pragma unroll
+            for (int g = 0; g < GL; ++g) {
+                if (FAST || g < a.ga) {
+                    const double s1 = lanes_sum<LT>(acc_re[g]), s2 = lanes_sum<LT>(acc_im[g]);
+                    if (lane == 0) {
+                        unsafeAtomicAdd(rec + g, s1);
+                        unsafeAtomicAdd(rec + a.ga + g, s2);
+                    }
+                    acc_re[g] = acc_im[g] = 0.0;
+                }
+                if (g < a.gd) {
+                    const double s3 = lanes_sum<LT>(acc_det[g]);
+                    if (lane == 0) unsafeAtomicAdd(rec + 2 * a.ga + g, s3);
+                    acc_det[g] = 0.0;
+                }
+            }
+            if (a.want_tau) {
+                const double s4 = lanes_sum<LT>(acc_tau);
+                if (lane == 0) unsafeAtomicAdd(rec + a.NC, s4);
+                acc_tau = 0.0;
+            }
+        }
+        vprev = v;
+    }
+    {   // cotangent of the initial point (vprev = entry 0 = psi0)
+        const double w = weight(inj);
+        mu.x += inj.gs.x + w * vprev.x;
+        mu.y += inj.gs.y + w * vprev.y;
     }
     if (active) {
         a.mu_out[boff + lane] = mu;

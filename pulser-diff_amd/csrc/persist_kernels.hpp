@@ -250,7 +250,9 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist(P
 // Per-exponential gradient sums stay in registers until the exponential is complete: one workgroup reduction each.
 // ---------------------------------------------------------------------------------------------------------------------
 struct PersistBwdArgs {
-    const double2* tape;      // [n_tsave][B][dim] saved states
+    const double2* tape;      // [n_tsave][B][dim] saved states; tape_full: [(n_factors + 1)][B][dim], entry f = input of factor f
+    int tape_full;            // the forward sweep kept every factor output: nothing is recomputed
+    const int32_t* save_entry;  // tape_full: tape entry of the state at save point k ([n_tsave])
     double2* chainbuf;        // [slots][B][dim]
     const double2* gstate;    // [n_tsave][B][dim] or nullptr
     const double* gexp;       // [n_obs][n_tsave][B] or nullptr

@@ -1155,7 +1155,12 @@ bool few_tiles(const Runtime& rt, bool with_gradients) {
 // The full per-factor tape (the adjoint sweep recomputes nothing) goes with the launch-per-factor ADJOINT kernels, chained or
 // direct (12 qubits: the one-launch forward sweep writes it); up to 11 qubits the adjoint sweep is one launch too and keeps
 // one state per tsave.
-bool full_tape_possible(const Plan& pl) { return pl.N > kPersistBwdMaxQubits && pl.n_pair == 0 && !pl.shard_bits; }
+// ... and the one-wave lane kernels (<= 6 qubits), whose tape-mode adjoint walks the factors without recomputing anything.
+bool full_tape_possible(const Plan& pl) {
+    if (pl.shard_bits) return false;
+    if (pl.N <= kLaneMaxQubits) return pl.n_pair <= kLanePairMax && pl.ga.n <= kPersistGroups && pl.gd.n <= kPersistGroups;
+    return pl.N > kPersistBwdMaxQubits && pl.n_pair == 0;
+}
 
 // common prologue of forward / backward: plan, (optional) stats, carve, upload metadata, expand coefficients, udiag.
 // With `info` given nothing in here waits for the device.
@@ -1792,6 +1797,16 @@ int launch_persist_bwd_t(const PersistBwdArgs& pa, int B, hipStream_t stream) {
 
 template <int LT, bool CPLX>
 int launch_lanes_bwd_t(const PersistBwdArgs& pa, int B, hipStream_t stream) {
+    if (pa.tape_full) {  // every factor input is on the tape: one descending walk, nothing recomputed
+        if (pa.ga == 1 && pa.gd <= 1 && pa.amask[0] == (1u << LT) - 1u && pa.pair.n == 0)
+            hipLaunchKernelGGL((k_lanes_bwd_tape<LT, CPLX, true>), dim3(B), dim3(64), 0, stream, pa);
+        else if (pa.ga <= 2 && pa.gd <= 2)
+            hipLaunchKernelGGL((k_lanes_bwd_tape<LT, CPLX, false, 2>), dim3(B), dim3(64), 0, stream, pa);
+        else
+            hipLaunchKernelGGL((k_lanes_bwd_tape<LT, CPLX, false>), dim3(B), dim3(64), 0, stream, pa);
+        LAUNCH_CHECK();
+        return RYDIFF_OK;
+    }
     if (pa.ga == 1 && pa.gd <= 1 && pa.amask[0] == (1u << LT) - 1u && pa.pair.n == 0)
         hipLaunchKernelGGL((k_lanes_bwd<LT, CPLX, true>), dim3(B), dim3(64), 0, stream, pa);
     else if (pa.ga <= 2 && pa.gd <= 2)
@@ -2165,9 +2180,11 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
 
     // small registers: the whole reverse sweep in one launch (k_persist_bwd)
     // (4096 amplitudes would need 8 per thread plus the accumulators: past the register file, so N = 12 keeps the launch-per-factor sweep)
-    const bool persisted = persist_enabled(rt) && pl.N <= kPersistBwdMaxQubits && !full_tape && pl.ga.n <= kPersistGroups &&
+    // (with the full tape: the lane kernels' tape-mode adjoint; variant 8 = LDS-tile kernels keeps one state per save point)
+    const bool lanes_tape = full_tape && lanes_enabled(rt.variant, pl.N, pl.ga.n, pl.gd.n, pl.n_pair);
+    const bool persisted = persist_enabled(rt) && pl.N <= kPersistBwdMaxQubits && (!full_tape || lanes_tape) && pl.ga.n <= kPersistGroups &&
                            pl.gd.n <= kPersistGroups &&
-                           rt.max_step_factors <= kStageChunk;
+                           (rt.max_step_factors <= kStageChunk || lanes_tape);
     if (persisted) {
         int n_factors = 0;
         rc = build_persist_table_device(rt, ws, stream, &n_factors);
@@ -2183,6 +2200,8 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
         PersistBwdArgs pa{};
         pa.gflags = dflags;
         pa.tape = tape;
+        pa.tape_full = full_tape ? 1 : 0;
+        pa.save_entry = reinterpret_cast<const int32_t*>(ws + pl.off_pm_first);
         pa.chainbuf = chainbuf;
         pa.gstate = gst;
         pa.gexp = have_gexp ? grad_expect : nullptr;

@@ -1,0 +1,7 @@
+set -u
+O=gpurun_out/r2p; mkdir -p $O
+timeout -k 10 900 python -m pytest tests -m gpu -q -x > $O/tests_all.log 2>&1; echo "all rc=$?" | tee -a $O/tests_all.log
+grep -E "passed|failed|FAILED|Error" $O/tests_all.log | head -20
+timeout -k 10 300 python tools/throughput_vs_n.py 1 7 > $O/throughput_1_7.txt 2>&1; grep -v amdgpu $O/throughput_1_7.txt
+timeout -k 10 200 python tools/time_epoch.py > $O/time_epoch.txt 2>&1; sed -n 2p $O/time_epoch.txt
+timeout -k 10 200 python tools/fuzz_parity.py 150 31 6 1 > $O/fuzz_1_6.txt 2>&1; tail -1 $O/fuzz_1_6.txt
