@@ -350,7 +350,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
             const double2* __restrict__ src = a.sh_self ? a.u + size_t(unsigned(a.b_first) + (bl ^ (1u << k))) * a.dim : a.sh_rem[k] + size_t(bl) * a.dim;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const double2 pv = stream_load(src + xg[r]);
+                const double2 pv = src[xg[r]];  // plain load: with every rank on one device each slab is read by its 3 partners too
                 remacc[r].x += kr * pv.x - ki * pv.y;
                 remacc[r].y += kr * pv.y + ki * pv.x;
             }
