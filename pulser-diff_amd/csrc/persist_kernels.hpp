@@ -314,8 +314,9 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist_b
         wt[r] = 0.0;
         ud[r] = active ? a.udiag[x] : 0.0;
         if (KEEPX) {
-            xend[r] = active ? a.tape[size_t(n_save) * sv + boff + x] : make_double2(0.0, 0.0);  // state at the final time
-            xnext[r] = active ? a.tape[size_t(n_save - 1) * sv + boff + x] : make_double2(0.0, 0.0);
+            // (tape_full: the tape holds every factor output; save point k sits at entry save_entry[k])
+            xend[r] = active ? a.tape[size_t(a.tape_full ? a.save_entry[n_save] : n_save) * sv + boff + x] : make_double2(0.0, 0.0);  // state at the final time
+            xnext[r] = active ? a.tape[size_t(a.tape_full ? a.save_entry[n_save - 1] : n_save - 1) * sv + boff + x] : make_double2(0.0, 0.0);
         }
     }
 #pragma unroll
@@ -325,7 +326,9 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist_b
     for (int g = 0; g < kPersistGroups; ++g) acc_re[g] = acc_im[g] = acc_det[g] = 0.0;
 
     // mu += grad_states[k] + 2 * sum_o grad_expect[o][k] * obs[o] * psi_k   (psi_k in registers)
-    auto state_elem = [&](int k, int r) -> double2 { return a.tape[size_t(k) * sv + boff + unsigned(r) * NT + tid0]; };
+    auto state_elem = [&](int k, int r) -> double2 {
+        return a.tape[size_t(a.tape_full ? a.save_entry[k] : k) * sv + boff + unsigned(r) * NT + tid0];
+    };
     auto inject = [&](int k, bool flagged) {
         if (!active) return;
         if (a.gstate) {
@@ -379,6 +382,7 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist_b
             else a.chainbuf[size_t(i) * sv + boff + idx] = val;
         };
         auto park_load = [&](int i, unsigned idx) -> double2 {
+            if (a.tape_full) return a.tape[size_t(fbeg + i + 1) * sv + boff + idx];  // x_{i+1} = output of the interval's factor i
             return park_lds ? park[(size_t(i) << LT) + idx] : a.chainbuf[size_t(i) * sv + boff + idx];
         };
 
@@ -393,7 +397,8 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist_b
 #pragma unroll
             for (int r = 0; r < R; ++r) xnext[r] = state_elem(k1 - 2, r);
         }
-        for (int i = 0; i + 1 < M; ++i) {
+        // (full tape: the factor inputs are already in global memory — nothing to recompute)
+        for (int i = 0; i + 1 < M && !a.tape_full; ++i) {
             unsigned tid = tid0;
             asm volatile("" : "+v"(tid));  // keep per-lane constants (signs, popcounts, LDS addresses) out of long-lived registers
             const PersistFactor pf = factor_at(fbeg + i);
@@ -461,6 +466,15 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist_b
         }
 
         // ---- adjoint of the interval's factors, last to first; v holds the input of the factor being processed
+        // (full tape: the inputs come from global memory, requested one factor ahead: vn = input of factor i - 1)
+        double2 vn[R];
+        if (a.tape_full && active) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                v[r] = M >= 2 ? park_load(M - 2, unsigned(r) * NT + tid0) : (KEEPX ? x0[r] : state_elem(k1 - 1, r));  // input of factor M-1
+                vn[r] = M >= 3 ? park_load(M - 3, unsigned(r) * NT + tid0) : (KEEPX ? x0[r] : state_elem(k1 - 1, r));  // input of factor M-2
+            }
+        }
         for (int i = M - 1; i >= 0; --i) {
             unsigned tid = tid0;
             asm volatile("" : "+v"(tid));
@@ -470,7 +484,15 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist_b
             const bool stage_end = (i == M - 1) || (factor_at(f + 1).stage != pf.stage);
             const bool stage_begin = (i == 0) || (factor_at(f - 1).stage != pf.stage);
             if (active) {
-                if (i != M - 1) {
+                if (a.tape_full) {
+                    if (i != M - 1) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            v[r] = vn[r];
+                            if (i >= 1) vn[r] = i >= 2 ? park_load(i - 2, unsigned(r) * NT + tid) : (KEEPX ? x0[r] : state_elem(k1 - 1, r));
+                        }
+                    }
+                } else if (i != M - 1) {
 #pragma unroll
                     for (int r = 0; r < R; ++r)
                         v[r] = i == 0 ? (KEEPX ? x0[r] : state_elem(k1 - 1, r)) : park_load(i - 1, unsigned(r) * NT + tid);

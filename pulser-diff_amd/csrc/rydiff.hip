@@ -1155,11 +1155,11 @@ bool few_tiles(const Runtime& rt, bool with_gradients) {
 // The full per-factor tape (the adjoint sweep recomputes nothing) goes with the launch-per-factor ADJOINT kernels, chained or
 // direct (12 qubits: the one-launch forward sweep writes it); up to 11 qubits the adjoint sweep is one launch too and keeps
 // one state per tsave.
-// ... and the one-wave lane kernels (<= 6 qubits), whose tape-mode adjoint walks the factors without recomputing anything.
+// ... and the one-launch adjoint sweeps (<= 11 qubits), which in tape mode walk the factors without recomputing anything.
 bool full_tape_possible(const Plan& pl) {
     if (pl.shard_bits) return false;
-    if (pl.N <= kLaneMaxQubits) return pl.n_pair <= kLanePairMax && pl.ga.n <= kPersistGroups && pl.gd.n <= kPersistGroups;
-    return pl.N > kPersistBwdMaxQubits && pl.n_pair == 0;
+    if (pl.N <= kPersistBwdMaxQubits) return pl.ga.n <= kPersistGroups && pl.gd.n <= kPersistGroups;
+    return pl.n_pair == 0;
 }
 
 // common prologue of forward / backward: plan, (optional) stats, carve, upload metadata, expand coefficients, udiag.
@@ -2180,16 +2180,16 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
 
     // small registers: the whole reverse sweep in one launch (k_persist_bwd)
     // (4096 amplitudes would need 8 per thread plus the accumulators: past the register file, so N = 12 keeps the launch-per-factor sweep)
-    // (with the full tape: the lane kernels' tape-mode adjoint; variant 8 = LDS-tile kernels keeps one state per save point)
+    // (with the full tape both one-launch adjoints — one wave up to 6 qubits, one workgroup up to 11 — walk the tape)
     const bool lanes_tape = full_tape && lanes_enabled(rt.variant, pl.N, pl.ga.n, pl.gd.n, pl.n_pair);
-    const bool persisted = persist_enabled(rt) && pl.N <= kPersistBwdMaxQubits && (!full_tape || lanes_tape) && pl.ga.n <= kPersistGroups &&
+    const bool persisted = persist_enabled(rt) && pl.N <= kPersistBwdMaxQubits && pl.ga.n <= kPersistGroups &&
                            pl.gd.n <= kPersistGroups &&
                            (rt.max_step_factors <= kStageChunk || lanes_tape);
     if (persisted) {
         int n_factors = 0;
         rc = build_persist_table_device(rt, ws, stream, &n_factors);
         if (rc) return rc;
-        if (rt.max_step_factors - 1 > pl.chain_slots) return fail(RYDIFF_EWORKSPACE, "internal: chain buffers too small");
+        if (!full_tape && rt.max_step_factors - 1 > pl.chain_slots) return fail(RYDIFF_EWORKSPACE, "internal: chain buffers too small");
         int32_t* dflags = nullptr;
         if (have_gexp) {  // stays on the device: the sweep skips save points without an expectation cotangent
             dflags = reinterpret_cast<int32_t*>(ws + pl.off_meta2);

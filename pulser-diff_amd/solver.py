@@ -192,9 +192,9 @@ class _RydbergEvolve(torch.autograd.Function):
             scratch = torch.empty(_native.PLAN_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
             info = _native.RydPlanInfo()
             # with the trajectory kept in the workspace tape, size the workspace for the backward sweep right away
-            # (7..11 qubits: the adjoint sweep is one launch that recomputes on chip — no full tape, no second plan call; up to
-            # 6 qubits the one-wave adjoint walks the full tape instead of recomputing)
-            if needs_grad and spec.tape in ("auto", "full") and (need_tape or spec.n_qubits >= 12 or spec.n_qubits <= 6):
+            # (every register size has a tape-mode adjoint: the launch-per-factor sweeps from 12 qubits on, the one-launch
+            # sweeps below, which otherwise recompute the factor inputs on chip)
+            if needs_grad and spec.tape in ("auto", "full"):
                 # FULL tape (every factor output kept, no recompute in the adjoint sweep) when HBM has room for it — also next
                 # to stored states (the states at the save points are then copied out of the tape), where it is granted
                 _native.check(L.rydiff_plan(ctypes.byref(call.problem), 2, 1, _ptr(scratch), stream, ctypes.byref(info)))
