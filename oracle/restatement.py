@@ -8,7 +8,9 @@ import this module; the product (``pulser-diff_amd/``) never does.
 Parity status: PINNED by the stored outputs of the reference's own tutorial notebook
 (tests/golden/notebook_pins.json, transcribed by tests/golden/extract_notebook_pins.py):
 KA-1 (DP5_SE, 160-point <sum Z>(t), printed amplitudes), KA-2..4 (KRYLOV_SE final <sum Z>),
-KA-5 (Adam loss traces = gradient pins).  The reference itself cannot be imported here
+KA-5 (Adam loss traces = gradient pins), KA-6..8 (docs/state_preparation.ipynb and docs/gate_optimization.ipynb: best loss and
+printed fidelity at the optimised parameters those notebooks print in full — Rydberg level 60, pulse shapes built with
+interpolate_sine, phases, all basis states as one batch).  The reference itself cannot be imported here
 (pyqtorch / pulser / pulser_simulation / qutip are absent; ordinary missing modules, no
 permission denial) and its tests hold no static vectors.
 
@@ -40,6 +42,10 @@ from torch import Tensor
 # pulser MockDevice, rydberg_level=70: interaction_coeff C6/hbar in rad/us * um^6
 # (used at pulser_diff/hamiltonian.py:343 via self._device.interaction_coeff).
 C6_MOCK_DEVICE = 5420158.53
+# pulser's C6 table for the two Rydberg levels the reference's material uses (VirtualDevice(rydberg_level=60) in
+# docs/state_preparation.ipynb / docs/gate_optimization.ipynb).  Level 60 is pinned by KA-6..8: with the level-70 value the
+# printed 99.79 % fidelity of KA-6 comes out as 2e-6.
+C6_RYDBERG_LEVEL = {60: 865723.02, 70: C6_MOCK_DEVICE}
 
 CDTYPE = torch.complex128
 RDTYPE = torch.float64
@@ -75,6 +81,22 @@ def constant_waveform(duration: int, value) -> Tensor:
 
 def custom_waveform(samples) -> Tensor:
     return _rd(samples)
+
+
+def sine_interpolation_matrix(num_values: int, duration: int) -> Tensor:
+    """pulser_diff/utils.py:136-180 (``s`` + ``interpolate_sine``): (duration, num_values) float32 weights; row k blends control
+    points idx-1 and idx, idx = floor(k / step), step = duration/(num_values+1), with the eased fraction (1 - cos(pi h))/2."""
+    step = duration / (num_values + 1)
+    mat = np.zeros((duration, num_values), dtype=np.float32)
+    for k in range(duration):
+        idx, r = divmod(k, step)  # python float divmod, as the reference computes it
+        idx = int(idx)
+        w = (1 + math.sin(math.pi * (r / step) - math.pi / 2)) / 2
+        if idx > 0:
+            mat[k, idx - 1] = 1 - w
+        if idx < num_values:
+            mat[k, idx] = w
+    return torch.from_numpy(mat)
 
 
 @dataclass

@@ -72,21 +72,102 @@ def resolve(v: Any, values: dict) -> Any:
 # device / register
 # ---------------------------------------------------------------------------------------------------------------
 @dataclass(frozen=True)
+class Channel:
+    """A device channel's identity and limits (pulser.channels: ``Rydberg.Global(max_abs_detuning, max_amp, ...)``).  The limits
+    are what optimisation scripts read back for their constraints (docs/gate_optimization.ipynb: ``device.channels[id].max_amp``);
+    ``None`` = unbounded, as on pulser's MockDevice."""
+
+    kind: str                      # "rydberg" | "raman" | "mw"
+    addressing: str                # "Global" | "Local"
+    max_abs_detuning: Optional[float] = None
+    max_amp: Optional[float] = None
+    max_duration: Optional[int] = None
+
+    @property
+    def basis(self) -> str:
+        return {"rydberg": "ground-rydberg", "raman": "digital", "mw": "XY"}[self.kind]
+
+    @property
+    def channel_id(self) -> str:
+        return f"{self.kind}_{self.addressing.lower()}"  # pulser's default ids on a VirtualDevice
+
+    def validate_pulse(self, pulse: "Pulse") -> None:
+        """pulser Channel.validate_pulse for concrete (non-parametrised, gradient-free) waveforms."""
+        if pulse.is_parametrized():
+            return
+        amp, det = pulse.amplitude.samples.detach(), pulse.detuning.samples.detach()
+        if self.max_amp is not None and bool((amp > self.max_amp * (1 + 1e-9)).any()):
+            raise ValueError("The pulse's amplitude goes over the maximum value allowed for the chosen channel.")
+        if self.max_abs_detuning is not None and bool((det.abs() > self.max_abs_detuning * (1 + 1e-9)).any()):
+            raise ValueError("The pulse's detuning values go out of the range allowed for the chosen channel.")
+        if self.max_duration is not None and int(pulse.duration) > self.max_duration:
+            raise ValueError("The pulse's duration exceeds the maximum duration allowed for the chosen channel.")
+
+
+class _ChannelKind:
+    def __init__(self, kind: str):
+        self._kind = kind
+
+    def Global(self, max_abs_detuning: Optional[float] = None, max_amp: Optional[float] = None,
+               max_duration: Optional[int] = None, **_ignored) -> Channel:
+        return Channel(self._kind, "Global", max_abs_detuning, max_amp, max_duration)
+
+    def Local(self, max_abs_detuning: Optional[float] = None, max_amp: Optional[float] = None,
+              max_duration: Optional[int] = None, **_ignored) -> Channel:
+        return Channel(self._kind, "Local", max_abs_detuning, max_amp, max_duration)
+
+
+Rydberg, Raman, Microwave = _ChannelKind("rydberg"), _ChannelKind("raman"), _ChannelKind("mw")
+
+# C6/hbar in rad/us*um^6 by Rydberg level (pulser's interaction-coefficient table).  Only the two levels that stored outputs of
+# the reference pin are listed: 70 (MockDevice; KA-1..KA-5) and 60 (the notebooks' VirtualDevice; KA-6..KA-8).
+C6_BY_RYDBERG_LEVEL = {60: 865723.02, 70: 5420158.53}
+
+
+@dataclass(frozen=True)
 class Device:
-    """The two device facts the hot path reads: ``interaction_coeff`` (hamiltonian.py:343) and basis support."""
+    """The device facts the hot path reads: ``interaction_coeff`` (hamiltonian.py:343), basis support, channel limits."""
 
     name: str = "MockDevice"
-    interaction_coeff: float = 5420158.53  # C6/hbar for Rydberg level 70, rad/us*um^6 (pinned by KA-1..KA-5)
+    interaction_coeff: float = C6_BY_RYDBERG_LEVEL[70]  # C6/hbar for Rydberg level 70
     # C3/hbar of the XY (microwave) mode, rad/us*um^3 (hamiltonian.py:365; pulser's MockDevice value as recalled: NOT pinned by
     # any stored output of the reference, whose tests and notebooks never run the XY mode)
     interaction_coeff_xy: float = 3700.0
     supported_bases: frozenset = frozenset({"ground-rydberg", "digital", "XY"})
     supports_slm_mask: bool = True
     max_atom_num: Optional[int] = None
+    dimensions: int = 3
+    rydberg_level: int = 70
+    channel_objects: tuple = (Channel("rydberg", "Global"), Channel("rydberg", "Local"), Channel("raman", "Global"),
+                              Channel("raman", "Local"), Channel("mw", "Global"))
+
+    @property
+    def channels(self) -> dict:
+        """channel id -> Channel (pulser Device.channels)."""
+        return {c.channel_id: c for c in self.channel_objects}
 
     def validate_register(self, register: "Register") -> None:
         if self.max_atom_num is not None and len(register.qubit_ids) > self.max_atom_num:
             raise ValueError(f"The number of atoms ({len(register.qubit_ids)}) exceeds the device maximum.")
+        dim = next(iter(register.qubits.values())).numel()
+        if dim > self.dimensions:
+            raise ValueError(f"All qubit positions must be at most {self.dimensions}D vectors.")
+
+
+def VirtualDevice(name: str, dimensions: int, rydberg_level: int = 70, channel_objects: tuple = (), max_atom_num: Optional[int] = None,
+                  interaction_coeff_xy: float = 3700.0, supports_slm_mask: bool = True, **_ignored) -> Device:
+    """pulser.devices.VirtualDevice for the fields this backend reads.  ``rydberg_level`` selects C6 from the table above; a
+    level outside it needs the number from Pulser (it cannot be derived here)."""
+    if rydberg_level not in C6_BY_RYDBERG_LEVEL:
+        raise NotImplementedError(f"C6 for Rydberg level {rydberg_level} is not tabulated here (levels: "
+                                  f"{sorted(C6_BY_RYDBERG_LEVEL)}); build Device(interaction_coeff=...) with Pulser's value.")
+    ids = [c.channel_id for c in channel_objects]
+    if len(set(ids)) != len(ids):
+        raise ValueError("Channel ids must be unique.")
+    return Device(name=name, interaction_coeff=C6_BY_RYDBERG_LEVEL[rydberg_level], interaction_coeff_xy=interaction_coeff_xy,
+                  supported_bases=frozenset(c.basis for c in channel_objects), supports_slm_mask=supports_slm_mask,
+                  max_atom_num=max_atom_num, dimensions=dimensions, rydberg_level=rydberg_level,
+                  channel_objects=tuple(channel_objects))
 
 
 MockDevice = Device()
@@ -118,9 +199,11 @@ class Register:
     @classmethod
     def rectangle(cls, rows: int, columns: int, spacing: float = 4.0, prefix: str = "q") -> "Register":
         # pulser Register.rectangle: column index fastest, centred on the origin
-        coords = np.array([[c, r] for r in range(rows) for c in range(columns)], dtype=float) * spacing
-        coords -= coords.mean(axis=0)
-        return cls.from_coordinates(coords, prefix)
+        # `spacing` may be a (1-element) tensor, as in the reference's notebooks; a leaf requiring grad stays differentiable
+        grid = torch.tensor([[c, r] for r in range(rows) for c in range(columns)], dtype=RD)
+        coords = grid * (spacing.to(RD).reshape(()) if isinstance(spacing, Tensor) else float(spacing))
+        coords = coords - coords.mean(dim=0)
+        return cls.from_coordinates(list(coords), prefix)
 
     @classmethod
     def square(cls, side: int, spacing: float = 4.0, prefix: str = "q") -> "Register":
@@ -417,6 +500,7 @@ class Sequence:
         self.register = register
         self.device = device
         self._channels: dict[str, ChannelInfo] = {}
+        self._device_channel: dict[str, Channel] = {}
         self._schedule: dict[str, list] = {}
         self._targets: dict[str, frozenset] = {}
         self._slm_mask_targets: set = set()
@@ -443,6 +527,7 @@ class Sequence:
             raise TypeError(f"Did not receive values for variables: {sorted(missing)}")
         out = Sequence(self.register, self.device)
         out._channels = dict(self._channels)
+        out._device_channel = dict(self._device_channel)
         out._targets = dict(self._targets)
         out._slm_mask_targets = set(self._slm_mask_targets)
         out._slm_mask_time = list(self._slm_mask_time)
@@ -463,12 +548,15 @@ class Sequence:
             raise ValueError("The given name is already in use.")
         if channel_id not in self._CHANNELS:
             raise ValueError(f"Channel {channel_id!r} is not supported by this backend.")
+        if channel_id not in self.device.channels:
+            raise ValueError(f"No channel {channel_id} in the device.")
         info = self._CHANNELS[channel_id]
         if self._channels and (info.basis == "XY") != any(c.basis == "XY" for c in self._channels.values()):
             raise ValueError("XY (microwave) channels cannot be combined with channels of the other bases.")
         if info.basis == "XY" and self._magnetic_field is None:
             self._magnetic_field = torch.tensor([0.0, 0.0, 30.0], dtype=RD)  # pulser's default field (along z)
         self._channels[name] = info
+        self._device_channel[name] = self.device.channels[channel_id]
         self._schedule[name] = []
         if info.addressing == "Global":
             self._targets[name] = frozenset(self.register.qubit_ids)
@@ -490,6 +578,7 @@ class Sequence:
             raise ValueError("Use the name of a declared channel.")
         if not self._targets[channel]:
             raise ValueError("Local channel has no target: call `target` first.")
+        self._device_channel[channel].validate_pulse(pulse)
         if self._slm_mask_targets and not self._slm_mask_time and self._channels[channel].addressing == "Global":
             ti = self.get_duration(channel)
             if not is_param(pulse.duration):

@@ -1,0 +1,200 @@
+"""The reference's two optimal-control notebooks (docs/state_preparation.ipynb, docs/gate_optimization.ipynb) through QuantumModel on
+the native backend.  Those notebooks print their optimised parameters in full together with the loss reached
+(tests/golden/notebook_pins.json, KA-6..KA-8).  The native DP5_SE forward at those parameters is held to two bars: the oracle's
+continuous-time solution of the same interpolated H(t) (1e-8: DP5_SE here means that solution) and the printed numbers
+(2e-5: the reference's own Dormand-Prince error at its default tolerances, which the oracle's DP5 restatement reproduces to 2e-6 in
+tests/test_oracle_pins.py).  The native adjoint must give the oracle's gradients for the same set-up, and a short Adam run must
+actually descend."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import restatement as R
+from pulser_diff_amd import pulses as pl
+from pulser_diff_amd.model import QuantumModel
+from pulser_diff_amd.solver import SolverType
+from pulser_diff_amd.utils import basis_state, interpolate_sine, kron, trace
+
+pytestmark = pytest.mark.gpu
+PINS = json.loads((Path(__file__).parent / "golden" / "notebook_pins.json").read_text())
+HMAT = torch.tensor([[1, 1], [1, -1]], dtype=torch.complex128) / 2 ** 0.5
+
+
+def _device(max_abs_detuning):
+    return pl.VirtualDevice(name="MockDevice", dimensions=2, rydberg_level=60,
+                            channel_objects=(pl.Rydberg.Global(max_abs_detuning, 12.566370614359172, max_duration=None),))
+
+
+def _shaped_model(device, n_qubits, spacing, n_param, gamma, amp_init, det_init, solver=SolverType.DP5_SE, initial_state=None,
+                  duration=1100):
+    seq = pl.Sequence(pl.Register.rectangle(1, n_qubits, torch.tensor([spacing])), device)
+    seq.declare_channel("rydberg_global", "rydberg_global")
+    amp_var = seq.declare_variable("amp_custom", size=duration)
+    det_var = seq.declare_variable("det_custom", size=duration)
+    seq.add(pl.Pulse(pl.CustomWaveform(amp_var), pl.CustomWaveform(det_var), 0.0), "rydberg_global")
+    channel = device.channels["rydberg_global"]
+    interp = interpolate_sine(n_param, duration)
+    shapes = {"amp_custom": ((amp_init,), lambda p: interp.to(p.dtype) @ (int(channel.max_amp) * torch.sigmoid(gamma * p))),
+              "det_custom": ((det_init,), lambda p: interp.to(p.dtype) @ (int(channel.max_abs_detuning) * torch.tanh(gamma * p)))}
+    return QuantumModel(seq, shapes, sampling_rate=0.05, solver=solver, initial_state=initial_state)
+
+
+def _state_infidelity(model, n_qubits):
+    target = basis_state(2 ** n_qubits, 0).to(torch.complex128)
+    _, states = model.forward()
+    return 1 - torch.abs(target.to(states.device).mH @ states[-1]).squeeze() ** 2
+
+
+def _gate_infidelity(model, n_qubits):
+    target = kron(*[HMAT] * n_qubits)
+    _, states = model.forward()
+    gate = states[-1]
+    return 1 - abs(trace(target.to(gate.device).mH @ gate)) / target.shape[0]
+
+
+def _oracle_final(seq, n_qubits, spacing, psi0):
+    coords = torch.tensor([[spacing * (i - (n_qubits - 1) / 2), 0.0] for i in range(n_qubits)], dtype=torch.float64)
+    terms = R.build_terms(seq, coords, 0.05, c6=R.C6_RYDBERG_LEVEL[60])
+    ts = R.evaluation_times(seq.tot_duration, 0.05).numpy()
+    return torch.from_numpy(R.continuous_solution(terms, psi0, ts[[0, -1]])[-1])
+
+
+def _oracle_shaped_seq(pin, n_param, gamma, max_det):
+    mat = R.sine_interpolation_matrix(n_param, 1100)
+    return R.concat_pulses([(mat @ (12 * torch.sigmoid(gamma * _printed(pin, "amp_custom_0"))),
+                             mat @ (max_det * torch.tanh(gamma * _printed(pin, "det_custom_0"))), 0.0)])
+
+
+def _printed(pin, name):
+    return torch.tensor(pin["parameters"][name])  # float32, like the notebooks' leaves
+
+
+def test_interpolate_sine_is_the_oracles_matrix():
+    for n_param, duration in ((30, 1100), (20, 1100), (3, 17)):
+        assert torch.equal(interpolate_sine(n_param, duration), R.sine_interpolation_matrix(n_param, duration))
+
+
+def test_ka6_state_preparation_printed_loss(cuda_device):
+    pin = PINS["ka6_state_preparation"]
+    model = _shaped_model(_device(6.28), 6, 7.0, 30, 0.02, _printed(pin, "amp_custom_0"), _printed(pin, "det_custom_0"))
+    assert sorted(n for n, _ in model.named_parameters()) == ["call_param_values.amp_custom_0", "call_param_values.det_custom_0"]
+    loss = float(_state_infidelity(model, 6).detach())
+    assert abs(loss - pin["best_loss"]) < 2e-5
+    assert f"{100 * (1 - loss):.2f}" == f"{pin['printed_fidelity_percent']:.2f}"
+    final = _oracle_final(_oracle_shaped_seq(pin, 30, 0.02, 6), 6, 7.0, R.all_ground_state(6).numpy())
+    assert abs(loss - (1 - final[0, 0].abs().item() ** 2)) < 1e-9
+    _, states = model.forward()
+    assert (states[-1].detach().cpu() - final).abs().max() < 1e-8
+
+
+def test_ka7_two_qubit_gate_printed_loss(cuda_device):
+    pin = PINS["ka7_gate_constant_pulses"]
+    device = _device(12.566370614359172)
+    seq = pl.Sequence(pl.Register.rectangle(1, 2, spacing=torch.tensor([6.5])), device)
+    seq.declare_channel("rydberg_global", "rydberg_global")
+    for i in range(8):
+        a, d, p = (seq.declare_variable(f"{k}_param_{i}") for k in ("amp", "det", "phase"))
+        seq.add(pl.Pulse.ConstantPulse(1050 // 8, a, d, p), "rydberg_global")
+    channel = device.channels["rydberg_global"]
+    constraints = {n: ({"min": 0.0, "max": int(channel.max_amp)} if "amp" in n else
+                       {"min": -channel.max_abs_detuning, "max": channel.max_abs_detuning})
+                   for n in pin["parameters"] if "phase" not in n}
+    model = QuantumModel(seq, {n: torch.tensor(v[0]) for n, v in pin["parameters"].items()}, constraints=constraints,
+                         sampling_rate=0.05, solver=SolverType.DP5_SE, initial_state=torch.eye(4))
+    model.check_constraints()  # the printed parameters already satisfy them (amp_param_6 sits on the lower bound)
+    assert all(p.item() == pytest.approx(pin["parameters"][n.split(".")[-1]][0], abs=1e-6) for n, p in model.named_parameters())
+    loss = float(_gate_infidelity(model, 2).detach())
+    assert abs(loss - pin["best_loss"]) < 2e-5
+    assert f"{100 * (1 - loss):.2f}" == f"{pin['printed_fidelity_percent']:.2f}"
+    # the final "state" is a unitary: all 4 columns evolved as one batch; and it is the oracle's
+    _, states = model.forward()
+    u = states[-1].detach()
+    assert (u.mH @ u - torch.eye(4, device=u.device)).abs().max() < 1e-10
+    par = {k: torch.tensor(v[0]) for k, v in pin["parameters"].items()}
+    oseq = R.concat_pulses([(R.constant_waveform(131, par[f"amp_param_{i}"]), R.constant_waveform(131, par[f"det_param_{i}"]),
+                             par[f"phase_param_{i}"]) for i in range(8)])
+    assert (u.cpu() - _oracle_final(oseq, 2, 6.5, np.eye(4, dtype=complex))).abs().max() < 1e-8
+
+
+def test_ka7_first_printed_loss_of_the_deterministic_start(cuda_device):
+    """gate_optimization.ipynb part 1 starts from all 24 parameters = 5.0 (no randomness): its first printed loss, 0.867522, is a
+    pure forward pin of phases + detuning + amplitude on the level-60 device."""
+    device = _device(12.566370614359172)
+    seq = pl.Sequence(pl.Register.rectangle(1, 2, spacing=torch.tensor([6.5])), device)
+    seq.declare_channel("rydberg_global", "rydberg_global")
+    names = []
+    for i in range(8):
+        a, d, p = (seq.declare_variable(f"{k}_param_{i}") for k in ("amp", "det", "phase"))
+        names += [f"amp_param_{i}", f"det_param_{i}", f"phase_param_{i}"]
+        seq.add(pl.Pulse.ConstantPulse(1050 // 8, a, d, p), "rydberg_global")
+    model = QuantumModel(seq, {n: torch.tensor(5.0) for n in names}, sampling_rate=0.05, solver=SolverType.DP5_SE,
+                         initial_state=torch.eye(4))
+    assert abs(float(_gate_infidelity(model, 2).detach()) - PINS["ka7_gate_constant_pulses"]["first_loss"]) < 2e-5
+
+
+def test_ka8_four_qubit_gate_printed_loss(cuda_device):
+    pin = PINS["ka8_gate_pulse_shape"]
+    model = _shaped_model(_device(12.566370614359172), 4, 6.5, 20, 0.05, _printed(pin, "amp_custom_0"), _printed(pin, "det_custom_0"),
+                          initial_state=torch.eye(16))
+    loss = float(_gate_infidelity(model, 4).detach())
+    assert abs(loss - pin["best_loss"]) < 2e-5
+    assert f"{100 * (1 - loss):.2f}" == f"{pin['printed_fidelity_percent']:.2f}"
+    _, states = model.forward()
+    final = _oracle_final(_oracle_shaped_seq(pin, 20, 0.05, 12), 4, 6.5, np.eye(16, dtype=complex))
+    assert (states[-1].detach().cpu() - final).abs().max() < 1e-8
+
+
+@pytest.mark.parametrize("case", ["state", "gate"])
+def test_shaped_pulse_gradients_match_oracle_autograd(cuda_device, case):
+    """d(infidelity)/d(control points) through the native adjoint = autograd through the oracle's dense map (KRYLOV_SE semantics on
+    both sides, seeded control points away from the optimum)."""
+    gen = torch.Generator().manual_seed(11)
+    n, n_param, gamma, spacing = (6, 30, 0.02, 7.0) if case == "state" else (4, 20, 0.05, 6.5)
+    max_det = 6 if case == "state" else 12
+    amp0 = (40 * torch.rand(n_param, generator=gen) - 20).to(torch.float64)
+    det0 = (40 * torch.rand(n_param, generator=gen) - 20).to(torch.float64)
+    init = None if case == "state" else torch.eye(2 ** n)
+    model = _shaped_model(_device(6.28 if case == "state" else 12.566370614359172), n, spacing, n_param, gamma, amp0.clone(), det0.clone(),
+                          solver=SolverType.KRYLOV_SE, initial_state=init)
+    loss = _state_infidelity(model, n) if case == "state" else _gate_infidelity(model, n)
+    loss.backward()
+    got = {k.split(".")[-1]: p.grad.detach().cpu() for k, p in model.named_parameters()}
+
+    a, d = amp0.clone().requires_grad_(True), det0.clone().requires_grad_(True)
+    mat = R.sine_interpolation_matrix(n_param, 1100).to(torch.float64)
+    seq = R.concat_pulses([(mat @ (12 * torch.sigmoid(gamma * a)), mat @ (max_det * torch.tanh(gamma * d)), 0.0)])
+    coords = torch.tensor([[spacing * (i - (n - 1) / 2), 0.0] for i in range(n)], dtype=torch.float64)
+    terms = R.build_terms(seq, coords, 0.05, c6=R.C6_RYDBERG_LEVEL[60])
+    ts = R.evaluation_times(seq.tot_duration, 0.05)
+    psi0 = R.all_ground_state(n) if case == "state" else torch.eye(2 ** n, dtype=torch.complex128)
+    final = R.krylov_map_dense(terms, psi0, ts)[-1]
+    if case == "state":
+        ref_loss = 1 - final[0, 0].abs() ** 2
+    else:
+        ref_loss = 1 - torch.trace(kron(*[HMAT] * n).mH @ final).abs() / 2 ** n
+    ref_loss.backward()
+    assert abs(float(loss) - float(ref_loss)) < 1e-10
+    for name, ref in (("amp_custom_0", a.grad), ("det_custom_0", d.grad)):
+        assert ref.abs().max() > 1e-6
+        assert (got[name] - ref).abs().max() < 1e-7 * ref.abs().max().item(), name  # relative: the state case's are ~1e-5
+
+
+def test_state_preparation_descends(cuda_device):
+    """40 Adam steps of the notebook's loop (lr 5, cosine annealing): from ~1 to well below, strictly better than the start."""
+    torch.manual_seed(1)  # seeds 1, 2, 4, 5 reach 99 % in 300 epochs; 0 and 3 sit in a local minimum near 70 % (the landscape's, not ours)
+    model = _shaped_model(_device(6.28), 6, 7.0, 30, 0.02, 2 * torch.rand(30) - 1.0, 2 * torch.rand(30) - 1.0)
+    opt = torch.optim.Adam(model.parameters(), lr=5.0)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=50)
+    losses = []
+    for _ in range(40):
+        loss = _state_infidelity(model, 6)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        sched.step()
+        model.update_sequence()
+        losses.append(float(loss.detach()))
+    assert losses[0] > 0.9 and min(losses) < 0.5 * losses[0], losses

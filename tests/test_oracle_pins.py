@@ -1,5 +1,6 @@
 """The CPU oracle against every static numerical pin the reference holds for this path: the stored outputs of
-docs/basic_usage.ipynb (tests/golden/notebook_pins.json).
+docs/basic_usage.ipynb (tests/golden/notebook_pins.json) and — KA-6..KA-8 — of
+docs/state_preparation.ipynb and docs/gate_optimization.ipynb, which print their optimised parameters in full.
 
 Tolerances = print precision of the stored outputs (4 decimals -> 1e-4 (+DP5 error), 6-decimal loss traces -> 1e-6).
 These validate conventions (C6, basis order, waveform normalisation, sampling-grid quirks, right-endpoint Krylov
@@ -191,3 +192,86 @@ def test_master_equation_pin_dephasing_expectation_and_first_losses():
 
     losses = _adam_trace([omega, area], model, 0.05, 2, clamp=lambda: omega.clamp_(4.5, 5.5))
     assert np.abs(np.array(losses) - np.array(ref["losses"][:2])).max() < 2e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# KA-6..KA-8: the two optimal-control notebooks.  Their random initial parameters are not stored but the optimised ones are
+# (4 decimals), with the loss they reach (16 digits): the forward pass at those parameters must reproduce it.  At an optimum
+# the loss is flat in the parameters, so the 4-decimal rounding moves it by ~1e-6 only.
+# ---------------------------------------------------------------------------------------------------------------------
+C6_LEVEL_60 = R.C6_RYDBERG_LEVEL[60]
+
+
+def _chain(n, spacing):
+    return torch.tensor([[spacing * (i - (n - 1) / 2), 0.0] for i in range(n)], dtype=torch.float64)
+
+
+def _shaped_pulse(pin, n_param, duration, gamma, max_amp, max_det):
+    """The notebooks' custom_wf_amp / custom_wf_det, in float32 like their leaves."""
+    mat = R.sine_interpolation_matrix(n_param, duration)
+    amp = mat @ (max_amp * torch.sigmoid(gamma * torch.tensor(pin["parameters"]["amp_custom_0"])))
+    det = mat @ (max_det * torch.tanh(gamma * torch.tensor(pin["parameters"]["det_custom_0"])))
+    return R.concat_pulses([(amp, det, 0.0)])
+
+
+def _final_dp5(seq, coords, psi0, rate=0.05):
+    terms = R.build_terms(seq, coords, rate, c6=C6_LEVEL_60)
+    ts = R.evaluation_times(seq.tot_duration, rate)
+    return R.dp5_solve(R.make_rhs(terms), psi0, ts.numpy())[-1]
+
+
+def _gate_infidelity(target, gate):
+    return 1 - abs(np.trace(target.conj().T @ gate)) / target.shape[0]
+
+
+def _hadamards(n):
+    h = np.array([[1, 1], [1, -1]]) / np.sqrt(2)
+    out = h
+    for _ in range(n - 1):
+        out = np.kron(out, h)
+    return out
+
+
+def test_ka6_state_preparation_fidelity_at_printed_parameters():
+    """state_preparation.ipynb: 6 qubits 7 um apart, VirtualDevice(rydberg_level=60), Rydberg.Global(6.28, 12.566): amplitude
+    int(12.566)*sigmoid, detuning int(6.28)*tanh, 30 control points, 1100 ns, DP5_SE at rate 0.05; target = basis state 0."""
+    pin = PINS["ka6_state_preparation"]
+    seq = _shaped_pulse(pin, 30, 1100, 0.02, 12, 6)
+    final = _final_dp5(seq, _chain(6, 7.0), R.all_ground_state(6).numpy())
+    loss = 1 - abs(final[0, 0]) ** 2
+    assert abs(loss - pin["best_loss"]) < 5e-6
+    assert f"{100 * (1 - loss):.2f}" == f"{pin['printed_fidelity_percent']:.2f}"
+    # the level-70 coefficient is off by orders of magnitude here: this pins C6(level 60)
+    t70 = R.build_terms(seq, _chain(6, 7.0), 0.05)
+    ts = R.evaluation_times(seq.tot_duration, 0.05)
+    wrong = R.dp5_solve(R.make_rhs(t70), R.all_ground_state(6).numpy(), ts.numpy())[-1]
+    assert abs(wrong[0, 0]) ** 2 < 1e-3
+
+
+def test_ka7_two_qubit_gate_with_constant_pulses_and_phases():
+    """gate_optimization.ipynb part 1: 8 constant pulses of 1050 // 8 ns with (amplitude, detuning, phase) each, 2 qubits 6.5 um
+    apart, the 4 basis states evolved as one batch (initial_state = eye(4)); loss = 1 - |tr(H2^dagger U)| / 4."""
+    pin = PINS["ka7_gate_constant_pulses"]
+    par = {k: torch.tensor(v[0]) for k, v in pin["parameters"].items()}  # float32 leaves
+    d = 1050 // 8
+    seq = R.concat_pulses([(R.constant_waveform(d, par[f"amp_param_{i}"]), R.constant_waveform(d, par[f"det_param_{i}"]),
+                            par[f"phase_param_{i}"]) for i in range(8)])
+    gate = _final_dp5(seq, _chain(2, 6.5), np.eye(4, dtype=complex))
+    loss = _gate_infidelity(_hadamards(2), gate)
+    assert abs(loss - pin["best_loss"]) < 2e-6
+    assert f"{100 * (1 - loss):.2f}" == f"{pin['printed_fidelity_percent']:.2f}"
+    # that run starts from all parameters = 5.0: its first printed loss is a forward pin too (6 decimals)
+    five = torch.tensor(5.0)
+    start = R.concat_pulses([(R.constant_waveform(d, five), R.constant_waveform(d, five), five)] * 8)
+    first = _gate_infidelity(_hadamards(2), _final_dp5(start, _chain(2, 6.5), np.eye(4, dtype=complex)))
+    assert abs(first - pin["first_loss"]) < 2e-6
+
+
+def test_ka8_four_qubit_gate_with_shaped_pulse():
+    """gate_optimization.ipynb part 2: 4 qubits, 20 control points, gamma 0.05, both limits int(12.566) = 12, 16 columns."""
+    pin = PINS["ka8_gate_pulse_shape"]
+    seq = _shaped_pulse(pin, 20, 1100, 0.05, 12, 12)
+    gate = _final_dp5(seq, _chain(4, 6.5), np.eye(16, dtype=complex))
+    loss = _gate_infidelity(_hadamards(4), gate)
+    assert abs(loss - pin["best_loss"]) < 2e-6
+    assert f"{100 * (1 - loss):.2f}" == f"{pin['printed_fidelity_percent']:.2f}"
