@@ -62,6 +62,9 @@ class ProblemSpec:
         return _SOLVER_CODE[self.solver]
 
 
+_SMALL_TAPE_BYTES = 64 << 20  # a full tape below this size is taken without consulting the allocator
+
+
 def tolerance_from_options(options: dict[str, Any]) -> float:
     unknown = set(options) - _KNOWN_OPTIONS
     if unknown:
@@ -198,9 +201,11 @@ class _RydbergEvolve(torch.autograd.Function):
                 # FULL tape (every factor output kept, no recompute in the adjoint sweep) when HBM has room for it — also next
                 # to stored states (the states at the save points are then copied out of the tape), where it is granted
                 _native.check(L.rydiff_plan(ctypes.byref(call.problem), 2, 1, _ptr(scratch), stream, ctypes.byref(info)))
-                free_bytes, _total = torch.cuda.mem_get_info(dev)
-                reusable = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-                fits = spec.tape == "full" or info.workspace_bytes < 0.8 * (free_bytes + reusable)
+                fits = spec.tape == "full" or info.workspace_bytes < _SMALL_TAPE_BYTES
+                if not fits:  # the allocator queries cost ~0.3 ms of host time: only asked when the answer is not obvious
+                    free_bytes, _total = torch.cuda.mem_get_info(dev)
+                    reusable = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+                    fits = info.workspace_bytes < 0.8 * (free_bytes + reusable)
                 if fits and (need_tape or info.tape_mode == 2):
                     need_tape = 2
             if need_tape != 2:

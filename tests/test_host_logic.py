@@ -387,3 +387,39 @@ def test_arbitrary_phase_pulse_turns_the_phase_into_detuning():
     # integrating the detuning back gives the phase (up to its constant)
     back = float(p.phase) - torch.cumsum(det[1:], 0) * 1e-3
     assert torch.allclose(back, phase.samples[1:], atol=1e-12)
+
+
+def test_virtual_device_channels_and_limits():
+    """pulser.devices.VirtualDevice / pulser.channels.Rydberg as the reference's optimal-control notebooks use them
+    (docs/state_preparation.ipynb cell 1, docs/gate_optimization.ipynb cells 1, 5): C6 by Rydberg level, `device.channels[id]`
+    limits, only the device's channels can be declared, concrete pulses are held to the limits, parametrised ones are not."""
+    dev = pl.VirtualDevice(name="MockDevice", dimensions=2, rydberg_level=60,
+                           channel_objects=(pl.Rydberg.Global(6.28, 12.566370614359172, max_duration=None),))
+    assert dev.interaction_coeff == R.C6_RYDBERG_LEVEL[60] and pl.MockDevice.interaction_coeff == R.C6_MOCK_DEVICE
+    ch = dev.channels["rydberg_global"]
+    assert (int(ch.max_amp), int(ch.max_abs_detuning), ch.addressing, ch.basis) == (12, 6, "Global", "ground-rydberg")
+    assert set(pl.MockDevice.channels) == {"rydberg_global", "rydberg_local", "raman_global", "raman_local", "mw_global"}
+    with pytest.raises(NotImplementedError, match="Rydberg level 61"):
+        pl.VirtualDevice(name="d", dimensions=2, rydberg_level=61)
+    with pytest.raises(ValueError, match="unique"):
+        pl.VirtualDevice(name="d", dimensions=2, channel_objects=(pl.Rydberg.Global(), pl.Rydberg.Global()))
+
+    spacing = torch.tensor([7.0], requires_grad=True)
+    reg = pl.Register.rectangle(1, 3, spacing)  # tensor spacing, as in the notebooks; stays differentiable
+    assert [c.tolist() for c in reg.qubits.values()] == [[-7.0, 0.0], [0.0, 0.0], [7.0, 0.0]]
+    assert reg.qubits["q2"].requires_grad
+    with pytest.raises(ValueError, match="at most 2D"):
+        pl.Sequence(pl.Register({"a": (0.0, 0.0, 1.0)}), dev)
+
+    seq = pl.Sequence(reg, dev)
+    with pytest.raises(ValueError, match="No channel raman_global"):
+        seq.declare_channel("r", "raman_global")
+    seq.declare_channel("ch", "rydberg_global")
+    with pytest.raises(ValueError, match="amplitude goes over the maximum"):
+        seq.add(pl.Pulse.ConstantPulse(100, 13.0, 0.0, 0.0), "ch")
+    with pytest.raises(ValueError, match="detuning values go out of the range"):
+        seq.add(pl.Pulse.ConstantPulse(100, 1.0, -7.0, 0.0), "ch")
+    seq.add(pl.Pulse.ConstantPulse(100, 12.5, -6.2, 0.0), "ch")
+    seq.add(pl.Pulse.ConstantPulse(100, seq.declare_variable("omega"), 0.0, 0.0), "ch")  # parametrised: checked by the user's constraints
+    built = seq.build(omega=torch.tensor(3.0))
+    assert built.get_duration() == 200 and not built.is_parametrized()
