@@ -58,6 +58,8 @@ struct ChainArgs {
     const double* coef_sta;  // coefficient record of factor j+1
     long coef_bstride;
     double fb_r, fb_i;                 // beta_j
+    double fg_r, fg_i;                 // gamma_j (adjoint mode, recovered contraction: see REC in k_chain)
+    int completes;                     // this launch's finish stage yields the COMPLETE v_j (three-layout chains: the middle pass does not)
     double sg_r, sg_i, sb_r, sb_i;     // gamma_{j+1}, beta_{j+1}
     int lo, hs, hb;                    // layout: tile bits [0,lo) -> index bits [0,lo); tile bits [lo,LT) -> index bits [hs,hs+hb)
     uint32_t dim;
@@ -270,9 +272,20 @@ __device__ unsigned long long g_timeline[4096 * 8];  // tuning builds: per-workg
 // RES: the vectors of a trajectory are meant to STAY in the XCD's L2 (trajectory-per-XCD placement): plain loads / stores instead
 // of the streaming (non-temporal) ones.  A template parameter on purpose: selecting the access flavour at run time made the
 // compiler merge both flavours into plain accesses and the 20-qubit pass lost its streaming hints (15.4 vs 13.9 us).
+// REC (adjoint of one global phase-free drive, BWD && FAST && !CPLX): the tape vector of a factor is read ONCE, by the launch that
+// completes the factor's adjoint.  With mu' = (gamma~ + beta~ (d + c F)) mu that launch holds mu (u), mu' (acc) and x (x_fin), so
+//     Re(beta <F mu, x>) = Re <mu' - (gamma~ + beta~ d) mu, x> / c                (elementwise: no partner sums, no second layout)
+// and the detuning / U_ij weights Re(beta conj(mu) x) are elementwise in (u, x_fin) as well.  The start stage then is the forward
+// start stage: the launch moves 3R + 2W instead of 4R + 2W.  The quotient loses log2(1 / |beta c|) bits, so a factor whose
+// |beta c| is below kRecMinBetaC (amplitude ~0: pulse edges, the padded last sample) keeps the exact contraction of the partner
+// sums with the tape vector in BOTH of its launches; the two launches of a factor take the same branch because they test the same
+// record and the same scalars.
+constexpr double kRecMinBetaC = 6.0e-5;  // 2^-14: at most 14 of 53 bits lost in the recovered contraction
+
 template <int LT, int LGT, bool CPLX, bool BWD, bool FAST = false, bool RES = false>
 __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     constexpr int NT = 1 << LGT, R = 1 << (LT - LGT);
+    constexpr bool REC = BWD && FAST && !CPLX;
     const int GA = FAST ? 1 : a.ga;            // amplitude groups looped over
     const int GD = FAST ? (a.gd ? 1 : 0) : a.gd;
     extern __shared__ __attribute__((aligned(16))) double2 tile[];
@@ -291,7 +304,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
             for (int w = 0; w < NW; ++w) sum += red[s * NW + w];
             double* dst;
             if (s < 2 * a.ga) dst = ge_fin_ + ((s & 1) ? a.ga : 0) + (s >> 1);
-            else if (s < 2 * a.ga + a.gd) dst = ge_sta_ + 2 * a.ga + (s - 2 * a.ga);
+            else if (s < 2 * a.ga + a.gd) dst = (REC ? ge_fin_ : ge_sta_) + 2 * a.ga + (s - 2 * a.ga);
             else dst = ge_sta_ + (((s - 2 * a.ga - a.gd) & 1) ? a.ga : 0) + ((s - 2 * a.ga - a.gd) >> 1);
             if (sum != 0.0) unsafeAtomicAdd(dst, sum);
         }
@@ -360,8 +373,15 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
 #pragma unroll
     for (int r = 0; r < R; ++r) dg[r] = a.utt[unsigned(r) * NT + tid];
     double2 xf[R], xs[R];
-    // the real-drive adjoint (no signed sums) has the registers to request the second tape vector up front as well
-    constexpr bool XS_EARLY = BWD && !CPLX;
+    // the real-drive adjoint (no signed sums) has the registers to request the second tape vector up front as well; REC reads it
+    // only for the rare factor that keeps the exact contraction (below)
+    constexpr bool XS_EARLY = BWD && !CPLX && !REC;
+    // REC: which scheme the finished / the started factor uses (wave-uniform; NaN-safe: !(>=) is the exact scheme)
+    bool exact_fin = true, exact_sta = true;
+    if constexpr (REC) {
+        exact_fin = !(fabs(a.coef_fin[bt * a.coef_bstride]) * sqrt(a.fb_r * a.fb_r + a.fb_i * a.fb_i) >= kRecMinBetaC);
+        exact_sta = !(fabs(a.coef_sta[bt * a.coef_bstride]) * sqrt(a.sb_r * a.sb_r + a.sb_i * a.sb_i) >= kRecMinBetaC);
+    }
     if (BWD) {
 #pragma unroll
         for (int r = 0; r < R; ++r) xf[r] = stream_load(a.x_fin + boff + xg[r]);
@@ -383,6 +403,34 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
         ge_fin = a.ge_fin + goff;
         ge_sta = a.ge_sta + goff;
     }
+
+    // interaction diagonal: tile-local table + remote part of this tile + cross terms of the tile bits that are in |r> (n = 1 - bit)
+    auto interaction_diagonal = [&](double (&du)[R]) {
+        double vloc[LT];
+        const double* __restrict__ vrow = a.vr + size_t(t_glob) * 16;
+#ifdef RYDIFF_ABLATE_COEF
+        for (int b2 = 0; b2 < LT; ++b2) vloc[b2] = a.sb_r;
+        double dlane = a.sb_i;
+        (void)vrow;
+#else
+#pragma unroll
+        for (int b2 = 0; b2 < LT; ++b2) vloc[b2] = vrow[b2];
+        double dlane = vrow[LT];
+#endif
+#pragma unroll
+        for (int b2 = 0; b2 < LGT; ++b2)
+            if (!(tid >> b2 & 1u)) dlane += vloc[b2];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            double d = dg[r] + dlane;
+#pragma unroll
+            for (int b2 = LGT; b2 < LT; ++b2)
+                if (!(r >> (b2 - LGT) & 1)) d += vloc[b2];
+            du[r] = d;
+        }
+    };
+    double du[R];
+    if constexpr (REC) interaction_diagonal(du);  // the finish stage needs it too
 
     if (a.has_p) {
         const double* __restrict__ cf = a.coef_fin + bt * a.coef_bstride;
@@ -412,7 +460,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
                     acc[r].y += k2r * ds[r].y + k2i * ds[r].x;
                 }
             }
-            if (BWD) {
+            if (BWD && exact_fin) {
                 // <F mu, x> with F Hermitian: z1 = sum conj(ts) x, z2 = sum conj(ds) x; dL/dRe c = Re(beta z1), dL/dIm c = Im(beta z2)
                 // (CPLX = false in the adjoint: real coefficients and a caller that only wants dL/dRe c — no signed sums at all)
                 double z1r = 0.0, z1i = 0.0, z2r = 0.0, z2i = 0.0;
@@ -427,6 +475,29 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
                 }
                 if (CPLX) park2<NW>(a.cb_fin_r * z1r - a.cb_fin_i * z1i, a.cb_fin_r * z2i + a.cb_fin_i * z2r, red, 2 * g, 2 * g + 1);
                 else park1<NW>(a.cb_fin_r * z1r - a.cb_fin_i * z1i, red, 2 * g);
+            }
+        }
+        if constexpr (REC) {
+            if (a.completes) {  // acc = mu' (before any injected cotangent), uu = mu, xf = the factor's input
+                // weights of d(x) in the gradient, Re(beta conj(mu) x): detuning group + U_ij accumulator
+                double sgd = 0.0, zr = 0.0;
+                const double cdet = GD ? cf[2] : 0.0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const double pr = a.cb_fin_r * uu[r].x + a.cb_fin_i * uu[r].y, pi = a.cb_fin_i * uu[r].x - a.cb_fin_r * uu[r].y;
+                    const double w = pr * xf[r].x - pi * xf[r].y;
+                    if (a.wtot) unsafeAtomicAdd(a.wtot + xg[r], w);
+                    const double cnt = GD ? double(a.dcnt[0] - __popc((xg[r] | rank_hi) & a.dmask[0])) : 0.0;
+                    sgd += w * cnt;
+                    if (!exact_fin) {  // Re <mu' - (gamma~ + beta~ d) mu, x>
+                        const double d = du[r] + cdet * cnt;
+                        const double dr = a.fg_r + a.fb_r * d, di = a.fg_i + a.fb_i * d;
+                        const double wx = acc[r].x - (dr * uu[r].x - di * uu[r].y), wy = acc[r].y - (dr * uu[r].y + di * uu[r].x);
+                        zr += wx * xf[r].x + wy * xf[r].y;
+                    }
+                }
+                if (GD) park1<NW>(sgd, red, 2 * a.ga);
+                if (!exact_fin) park1<NW>(zr / cf[0], red, 0);
             }
         }
     } else {
@@ -463,7 +534,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
             }
         }
     }
-    if (BWD && !XS_EARLY && a.has_q) {  // issued here (not at the top) to stay inside the register budget of 1024-thread tiles
+    if (BWD && !XS_EARLY && a.has_q && (!REC || exact_sta)) {  // issued here (not at the top) to stay inside the register budget of 1024-thread tiles
 #pragma unroll
         for (int r = 0; r < R; ++r) xs[r] = stream_load(a.x_sta + boff + xg[r]);
     }
@@ -495,23 +566,9 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     RYDIFF_TL(4);
 
     const double* __restrict__ cf = a.coef_sta + bt * a.coef_bstride;
-    // interaction diagonal: remote part of this tile + cross terms of the tile bits that are in |r> (n = 1 - bit)
-    double vloc[LT];
-    const double* __restrict__ vrow = a.vr + size_t(t_glob) * 16;
-#ifdef RYDIFF_ABLATE_COEF
-    for (int b2 = 0; b2 < LT; ++b2) vloc[b2] = a.sb_r;
-    double dlane = a.sb_i;
-    (void)vrow;
-#else
-#pragma unroll
-    for (int b2 = 0; b2 < LT; ++b2) vloc[b2] = vrow[b2];
-    double dlane = vrow[LT];
-#endif
-#pragma unroll
-    for (int b2 = 0; b2 < LGT; ++b2)
-        if (!(tid >> b2 & 1u)) dlane += vloc[b2];
-    double rr[R];  // Re(beta conj(mu) x): weight of d(x) in the gradient
-    if (BWD) {
+    if constexpr (!REC) interaction_diagonal(du);
+    double rr[R];  // Re(beta conj(mu) x): weight of d(x) in the gradient (REC: taken by the launch that completes the factor)
+    if (BWD && !REC) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const double pr = a.cb_sta_r * acc[r].x + a.cb_sta_i * acc[r].y, pi = a.cb_sta_i * acc[r].x - a.cb_sta_r * acc[r].y;
@@ -528,10 +585,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     double2 q[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        double d = dg[r] + dlane;
-#pragma unroll
-        for (int b2 = LGT; b2 < LT; ++b2)
-            if (!(r >> (b2 - LGT) & 1)) d += vloc[b2];
+        double d = du[r];
         if (FAST) {
             if (GD) d += cf[2] * double(a.dcnt[0] - __popc((xg[r] | rank_hi) & a.dmask[0]));
         } else {
@@ -566,7 +620,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
                 q[r].y += k2r * ds[r].y + k2i * ds[r].x;
             }
         }
-        if (BWD) {
+        if (BWD && exact_sta) {
             double z1r = 0.0, z1i = 0.0, z2r = 0.0, z2i = 0.0;
 #pragma unroll
             for (int r = 0; r < R; ++r) {

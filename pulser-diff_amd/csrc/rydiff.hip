@@ -1422,6 +1422,7 @@ struct ChainStep {
     int fin_stage, sta_stage;
     FactorScalars fin, sta;
     int has_p, has_q, write_v;
+    bool completes = true;  // the finish stage yields the complete vector (false: middle pass of a three-layout chain)
     int layout, prev_layout;
     uint32_t covered_bits = 0;  // index bits whose flips the incoming partial already contains
     // backward mode
@@ -1505,6 +1506,9 @@ int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, const BatchSl
     ca.coef_bstride = pl.Bc > 1 ? long(pl.stages.size()) * pl.NC : 0;
     ca.fb_r = cs.fin.br;
     ca.fb_i = cs.fin.bi;
+    ca.fg_r = cs.fin.gr;
+    ca.fg_i = cs.fin.gi;
+    ca.completes = (cs.has_p && cs.completes) ? 1 : 0;
     ca.sg_r = cs.sta.gr;
     ca.sg_i = cs.sta.gi;
     ca.sb_r = cs.sta.br;
@@ -1614,6 +1618,7 @@ int run_chain(const Runtime& rt, char* ws, const std::vector<ChainItem>& items, 
         cs.p = cs.has_p ? ppsel(k - 1) : nullptr;
         cs.q_out = cs.has_q ? ppsel(k) : nullptr;
         cs.write_v = cs.has_p;
+        cs.completes = st.completes;
         if (cs.has_p) {
             cs.v_out = st.completes ? dst(st.fin) : ppsel(k);  // a middle pass hands the extended partial on
             cs.fin_stage = items[st.fin].stage;
@@ -1672,6 +1677,7 @@ int run_chain_bwd(const Runtime& rt, char* ws, const std::vector<ChainItem>& ite
         cs.p = cs.has_p ? ppsel(k - 1) : nullptr;
         cs.q_out = cs.has_q ? ppsel(k) : nullptr;
         cs.write_v = cs.has_p;
+        cs.completes = st.completes;
         cs.wtot = wtot;
         if (cs.has_p) {
             const int f = M - 1 - st.fin;  // forward factor whose adjoint this launch extends / completes

@@ -625,3 +625,57 @@ def test_state_cotangents_at_every_save_point(cuda_device, n_qubits, variants, t
     for v in variants:
         for name, a, b in zip(("amp", "det", "u", "tsave", "psi0"), native(v), ref):
             assert rel_err(a, b) < tol, (v, name)
+
+
+@pytest.mark.parametrize("n_qubits,variant,with_det,batch_tables,tape,solver_name", [
+    (13, 4, True, 1, "full", "KRYLOV_SE"), (14, 2, False, 1, "steps", "KRYLOV_SE"), (21, 7, True, 1, "full", "KRYLOV_SE"),
+    (14, 4, True, 3, "full", "KRYLOV_SE"), (13, 10, True, 1, "full", "KRYLOV_SE"), (13, 2, True, 1, "full", "DP5_SE")])
+def test_single_tape_read_adjoint_on_both_sides_of_its_switch(cuda_device, n_qubits, variant, with_det, batch_tables, tape, solver_name):
+    """The adjoint of ONE phase-free global drive on the chained tiles reads each tape vector once and recovers <F mu, x> from the
+    completed cotangent (chain_kernels.hpp, REC); a factor with |beta c| < 6e-5 keeps the exact partner-sum contraction in both of
+    its launches.  Amplitudes from exactly 0 (the padded sample) over 1e-6 ... 0.3 (around the switch) up to 7 rad/us, so that
+    consecutive factors take different branches; two / three tile layouts, 512 / 1024 threads, trajectory-per-XCD placement,
+    per-trajectory tables, both tape modes, both solvers.  Reference: the same problem as COMPLEX tables on the direct kernels
+    (one amplitude per thread, explicit partner reads; pinned to the oracle by tests/test_gpu_baseline_fixtures.py)."""
+    from pulser_diff_amd import _native
+    from pulser_diff_amd.solver import ProblemSpec, SolverType, evolve
+
+    solver = getattr(SolverType, solver_name)
+    n_samples = 14
+    terms = random_terms(n_qubits, n_samples, 0.002, seed=900 + n_qubits, local=False, phase=False)
+    amp_c, det, u, spec0 = to_native(terms, cuda_device, solver, store_states=False, batch_tables=batch_tables)
+    profile = torch.tensor([0.0, 1e-6, 3e-3, 0.04, 0.1, 0.16, 0.3, 1.2, 7.0, 3.0, 0.12, 0.2, 2e-2, 0.0], dtype=torch.float64)
+    amp_r = profile.to(cuda_device).repeat(batch_tables, 1, 1) * torch.linspace(1.0, 1.3, batch_tables, device=cuda_device)[:, None, None]
+    if not with_det:
+        det = det[:, :0]
+    tsave0 = torch.linspace(0, 0.0255, 7, dtype=torch.float64)
+    gen = torch.Generator().manual_seed(n_qubits + variant)
+    batch = max(batch_tables, 2)
+    psi = torch.randn(batch, 2**n_qubits, generator=gen, dtype=torch.complex128)
+    psi = (psi / psi.norm(dim=1, keepdim=True)).to(cuda_device)
+    obs = torch.rand(1, 2**n_qubits, generator=gen, dtype=torch.float64).to(cuda_device)
+    out = []
+    for amp, var in ((amp_r.to(torch.complex128), 1), (amp_r, variant)):
+        _native.set_kernel_variant(var)
+        try:
+            spec = ProblemSpec(spec0.n_qubits, spec0.dt, spec0.n_samples, spec0.amp_masks, spec0.det_masks if with_det else (), solver=solver,
+                               store_states=False, tape=tape)
+            leaves = [amp.clone().requires_grad_(True), det.clone().requires_grad_(True), u.clone().requires_grad_(True),
+                      tsave0.clone().requires_grad_(True), psi.clone().requires_grad_(True)]
+            _, expect = evolve(*leaves, spec, obs)
+            w = torch.linspace(0.3, 1.1, expect.shape[1], dtype=torch.float64, device=cuda_device)
+            (expect[0] * w[:, None]).sum().backward()
+            stats = dict(spec.options.get("_last_stats", {}))
+            out.append([expect.detach().cpu()] + [torch.zeros(0) if l.grad is None else l.grad.detach().cpu() for l in leaves] + [stats])
+        finally:
+            _native.set_kernel_variant(0)
+    assert out[1][-1].get("kernel_family") == "chained-tiles" and out[0][-1].get("kernel_family") == "direct"
+    out[0][1] = out[0][1].real
+    for name, ref, got in zip(("expect", "amp", "det", "u", "tsave", "psi0"), out[0][:-1], out[1][:-1]):
+        if ref.numel():
+            assert rel_err(got.numpy(), ref.numpy()) < 1e-10, name
+    # the amplitude gradient sample by sample (rel_err above is relative to the LARGEST entry): samples on either side of the switch
+    ga_ref, ga_got = out[0][1].reshape(batch_tables, -1), out[1][1].reshape(batch_tables, -1)
+    used = ga_ref.abs() > 0
+    assert used.sum() >= 6 * batch_tables
+    assert ((ga_got - ga_ref).abs()[used] / ga_ref.abs()[used]).max() < 1e-8
