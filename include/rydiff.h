@@ -147,6 +147,19 @@ typedef struct RydProblem {
      * trajectory would otherwise need n_tsave x 256 MiB).  Launch-per-factor kernels only (more than 12 qubits, or a
      * state-sharded run); not together with need_tape. */
     int32_t final_state_only;
+
+    /* Three-level registers (the reference's basis "all": r, g, h, hamiltonian.py:306-310) run as TWO qubits per atom — atom i =
+     * qubits (2i, 2i+1) = (a_i, b_i) with r = (0,1), g = (1,1), h = (1,0); the code (0,0) is never populated — with two
+     * generalisations of the terms above, both bit masks over TERM indices (bit k = term k):
+     *   amp_conditioned_terms: the flip of qubit j by term k acts only on amplitudes whose SIBLING qubit (j ^ 1) is in state 1:
+     *       g <-> r flips a_i where b_i = 1, g <-> h flips b_i where a_i = 1, and neither leaves the three valid codes;
+     *   det_ones_terms: term k weights the qubits of its mask that are in state 1 with MINUS its coefficient, i.e. contributes
+     *       2*det_k(t) * (0 - #ones) instead of 2*det_k(t) * (#zeros): on the valid codes n_g = a_i + b_i - 1, so the reference's
+     *       detuning on sigma_gg (hamiltonian.py:413) is an ordinary term on the a qubits plus a ones-counting term on the b qubits.
+     * All terms that address one qubit must agree on these flags; n_qubits must be even when any term is conditioned.  Such
+     * problems run on the generic one-amplitude-per-thread kernels (forward, adjoint, every gradient), any register size. */
+    uint64_t amp_conditioned_terms;
+    uint64_t det_ones_terms;
 } RydProblem;
 
 /* Result of rydiff_plan(): everything that depends on the VALUES in the coefficient tables. */

@@ -19,7 +19,7 @@ The golden vectors of the BASELINE shapes under tests/golden/*.npz are generated
 and — for gradients beyond dense H — autograd through the matrix-free Taylor map (krylov_map_matrix_free_torch), the three
 of which are checked against each other in tests/test_oracle_consistency.py.  reference_style_dense_H_t restates the
 reference's operator construction literally for every two-level basis (ground-rydberg, digital, XY), including the XY
-exchange exactly as the reference assembles it.
+exchange exactly as the reference assembles it; reference_style_dense_H_t_three_level does the same for the basis "all".
 
 Third-party owners of arithmetic that are NOT under /root/reference and are restated from
 their published behaviour: ``pyqtorch`` (unpinned, pyproject.toml:31) for sesolve
@@ -420,6 +420,53 @@ def reference_style_dense_H_t(coords: Tensor, amp_terms: list, det_terms: list, 
             ham = ham + ham_mat + ham_mat.mH
         for mat, val in amp_mats:
             ham_mat = mat * (val[i1] + (val[i2] - val[i1]) * (t - i1 * dt) / dt)
+            ham = ham + ham_mat + ham_mat.mH
+        return ham
+
+    return H_t
+
+
+def reference_style_dense_H_t_three_level(coords: Tensor, terms: list, dt: float, n_samples: int, c6: float = C6_MOCK_DEVICE):
+    """Literal, dense restatement of the reference's Hamiltonian in its three-level basis "all" (a ground-rydberg AND a digital
+    channel in one sequence; 3^n amplitudes, small registers; test infrastructure; no stored output of the reference pins it):
+
+      hamiltonian.py:306-310  basis order (r, g, h) = indices (0, 1, 2), projectors gr, hg, rr, gg, hh;
+      hamiltonian.py:409-414  a ground-rydberg channel drives sigma_gr = |g><r| and weights sigma_rr, a digital channel drives
+                              sigma_hg = |h><g| and weights sigma_gg (sic: the GROUND state), coefficients 0.5*amp*exp(-i*phase)
+                              and -0.5*det;
+      hamiltonian.py:333-344  van der Waals term 0.5*C6/r^6 on sigma_rr(q1) sigma_rr(q2)  (basis_name != "digital", :460);
+      hamiltonian.py:526-546  H(t) = 2*int_mat + sum_terms (M c(t) + (M c(t))^dagger) with the interpolation rule.
+
+    terms: [(basis "ground-rydberg" | "digital", kind "amp" | "det", coefficient array, atoms)]."""
+    coords = torch.as_tensor(coords, dtype=RDTYPE)
+    n = coords.shape[0]
+    ket = {b: torch.zeros(3, 1, dtype=CDTYPE) for b in "rgh"}
+    for i, b in enumerate("rgh"):
+        ket[b][i, 0] = 1.0
+    sigma = {ab: ket[ab[0]] @ ket[ab[1]].mH for ab in ("gr", "hg", "rr", "gg", "hh")}
+    eye = torch.eye(3, dtype=CDTYPE)
+
+    def build(ops: dict) -> Tensor:  # build_operator, hamiltonian.py:221-268
+        out = torch.ones(1, 1, dtype=CDTYPE)
+        for q in range(n):
+            out = torch.kron(out, ops.get(q, eye))
+        return out
+
+    dim = 3**n
+    int_mat = torch.zeros(dim, dim, dtype=CDTYPE)
+    for q1, q2 in itertools.combinations(range(n), 2):
+        dist = torch.linalg.norm(coords[q1] - coords[q2])
+        int_mat = int_mat + (0.5 * c6 / dist**6) * build({q1: sigma["rr"], q2: sigma["rr"]})
+    op_ids = {("ground-rydberg", "amp"): "gr", ("ground-rydberg", "det"): "rr", ("digital", "amp"): "hg", ("digital", "det"): "gg"}
+    mats = [(sum(build({q: sigma[op_ids[(basis, kind)]]}) for q in atoms), c) for basis, kind, c, atoms in terms]
+
+    def H_t(t):
+        if not isinstance(t, Tensor):
+            t = torch.tensor(t, dtype=RDTYPE)
+        i1, i2 = interp_indices(float(t), dt, n_samples)
+        ham = 2 * int_mat
+        for mat, val in mats:
+            ham_mat = mat * ((1.0 + 0.0j) * (val[i1] + (val[i2] - val[i1]) * (t - i1 * dt) / dt))
             ham = ham + ham_mat + ham_mat.mH
         return ham
 

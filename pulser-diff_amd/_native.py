@@ -60,6 +60,8 @@ class RydProblem(ctypes.Structure):
         ("shard_exchange", ctypes.c_void_p),
         ("shard_user", ctypes.c_void_p),
         ("final_state_only", ctypes.c_int32),
+        ("amp_conditioned_terms", ctypes.c_uint64),
+        ("det_ones_terms", ctypes.c_uint64),
     ]
 
 

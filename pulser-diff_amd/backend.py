@@ -11,8 +11,8 @@ What changes for a user switching over:
     trajectories and returns ``NoisyResults``; collapse-operator noise (dephasing, relaxation, depolarizing, eff_noise) and
     ``SolverType.DP5_ME`` run the master equation on a doubled register (``lindblad.py``) and return density matrices;
   * the digital basis, the XY mode (up to 8 qubits; its exchange exactly as the reference assembles it, see
-    ``hamiltonian.Hamiltonian.XY_HERMITIAN``) and SLM masks run on the same kernels; the three-level "all" basis (and with it
-    ``with_leakage``, which the reference only forwards to Pulser's NoiseModel) raises ``NotImplementedError``;
+    ``hamiltonian.Hamiltonian.XY_HERMITIAN``) and SLM masks run on the same kernels; the three-level "all" basis (a ground-rydberg
+    and a digital channel in one sequence) runs as two qubits per atom with conditioned flips (noiseless runs);
   * a training loop keeps ONE emulator and calls ``refresh_from_sequence`` per epoch (``model.QuantumModel`` does).
 """
 from __future__ import annotations
@@ -95,7 +95,8 @@ class TorchEmulator:
                                         compute_device=self._compute_device)
         self._eval_times_array: Tensor
         self.set_evaluation_times(evaluation_times)
-        self._meas_basis = self.samples_obj._measurement or self._hamiltonian.basis_name
+        # backend.py:141-147: the sequence's measurement basis, else the Hamiltonian's ("digital" for the three-level basis)
+        self._meas_basis = self.samples_obj._measurement or ("digital" if self._hamiltonian.basis_name == "all" else self._hamiltonian.basis_name)
         self.set_initial_state("all-ground")
         self.dist_dict: dict[str, Tensor] = {}
 
@@ -178,8 +179,11 @@ class TorchEmulator:
         if isinstance(state, str) and state == "all-ground":
             # kron of N |g> kets: |g> is basis state 1 of the ground-rydberg basis (r, g) -> last vector; it is basis state 0
             # of the digital basis (g, h), like |u> of the XY basis (u, d) (backend.py:266-271) -> first vector
-            psi = torch.zeros(2**n, 1, dtype=torch.complex128)
-            psi[-1 if self._hamiltonian.basis_name == "ground-rydberg" else 0, 0] = 1.0
+            dim = self._hamiltonian.dim
+            psi = torch.zeros(dim**n, 1, dtype=torch.complex128)
+            # position of |g> in the basis: 1 in (r, g) and in (r, g, h), 0 in (g, h); |u> of (u, d) is 0
+            g = 0 if self._hamiltonian.basis_name in ("digital", "XY") else 1
+            psi[sum(g * dim**k for k in range(n)), 0] = 1.0
             self._initial_state = psi
         else:
             shape = state.shape[0]
@@ -286,6 +290,9 @@ class TorchEmulator:
             solver = SolverType.DP5_ME
         if solver not in (SolverType.DP5_SE, SolverType.KRYLOV_SE, SolverType.DP5_ME):
             raise ValueError(f"Solver {solver} not available.")
+        if solver == SolverType.DP5_ME and self._hamiltonian.basis_name == "all":
+            raise NotImplementedError("The master-equation solver is not available in the three-level all-basis "
+                                      "(the reference admits no collapse-operator noise there, hamiltonian.py:98-103).")
 
         dev = self._compute_device
         ham = self._hamiltonian

@@ -487,7 +487,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
                     const double pr = a.cb_fin_r * uu[r].x + a.cb_fin_i * uu[r].y, pi = a.cb_fin_i * uu[r].x - a.cb_fin_r * uu[r].y;
                     const double w = pr * xf[r].x - pi * xf[r].y;
                     if (a.wtot) unsafeAtomicAdd(a.wtot + xg[r], w);
-                    const double cnt = GD ? double(a.dcnt[0] - __popc((xg[r] | rank_hi) & a.dmask[0])) : 0.0;
+                    const double cnt = GD ? double(a.dcnt[0] - popc_i((xg[r] | rank_hi) & a.dmask[0])) : 0.0;
                     sgd += w * cnt;
                     if (!exact_fin) {  // Re <mu' - (gamma~ + beta~ d) mu, x>
                         const double d = du[r] + cdet * cnt;
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
         for (int g = 0; g < GD; ++g) {
             double sgd = 0.0;
 #pragma unroll
-            for (int r = 0; r < R; ++r) sgd += rr[r] * double(a.dcnt[g] - __popc((xg[r] | rank_hi) & a.dmask[g]));
+            for (int r = 0; r < R; ++r) sgd += rr[r] * double(a.dcnt[g] - popc_i((xg[r] | rank_hi) & a.dmask[g]));
             park1<NW>(sgd, red, 2 * a.ga + g);
         }
     }
@@ -587,9 +587,9 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     for (int r = 0; r < R; ++r) {
         double d = du[r];
         if (FAST) {
-            if (GD) d += cf[2] * double(a.dcnt[0] - __popc((xg[r] | rank_hi) & a.dmask[0]));
+            if (GD) d += cf[2] * double(a.dcnt[0] - popc_i((xg[r] | rank_hi) & a.dmask[0]));
         } else {
-            for (int g = 0; g < a.gd; ++g) d += cf[2 * a.ga + g] * double(a.dcnt[g] - __popc((xg[r] | rank_hi) & a.dmask[g]));
+            for (int g = 0; g < a.gd; ++g) d += cf[2 * a.ga + g] * double(a.dcnt[g] - popc_i((xg[r] | rank_hi) & a.dmask[g]));
         }
         const double dr = a.sg_r + a.sb_r * d, di = a.sg_i + a.sb_i * d;
         q[r].x = dr * acc[r].x - di * acc[r].y;

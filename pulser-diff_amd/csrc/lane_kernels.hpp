@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64) void k_lanes_fwd(PersistArgs a) {
     double ud = 0.0, ob0 = 0.0;
     double cnt[kPersistGroups];
 #pragma unroll
-    for (int g = 0; g < kPersistGroups; ++g) cnt[g] = g < a.gd ? double(a.dcnt[g] - __popc(lane & a.dmask[g])) : 0.0;
+    for (int g = 0; g < kPersistGroups; ++g) cnt[g] = g < a.gd ? double(a.dcnt[g] - popc_i(lane & a.dmask[g])) : 0.0;
     if (active) {
         v = a.psi0[boff + lane];
         ud = a.udiag[lane];
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(64) void k_lanes_bwd(PersistBwdArgs a) {
     const double live = active ? 1.0 : 0.0;
     double cnt[kPersistGroups];
 #pragma unroll
-    for (int g = 0; g < kPersistGroups; ++g) cnt[g] = g < a.gd ? double(a.dcnt[g] - __popc(lane & a.dmask[g])) : 0.0;
+    for (int g = 0; g < kPersistGroups; ++g) cnt[g] = g < a.gd ? double(a.dcnt[g] - popc_i(lane & a.dmask[g])) : 0.0;
     const double ud = active ? a.udiag[lane] : 0.0;
     auto state_at = [&](int k) -> double2 {
         const double2 s = a.tape[size_t(k) * sv + boff + xl];
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(64) void k_lanes_bwd_tape(PersistBwdArgs a) {
     const double live = active ? 1.0 : 0.0;
     double cnt[kPersistGroups];
 #pragma unroll
-    for (int g = 0; g < kPersistGroups; ++g) cnt[g] = g < a.gd ? double(a.dcnt[g] - __popc(lane & a.dmask[g])) : 0.0;
+    for (int g = 0; g < kPersistGroups; ++g) cnt[g] = g < a.gd ? double(a.dcnt[g] - popc_i(lane & a.dmask[g])) : 0.0;
     const double ud = active ? a.udiag[lane] : 0.0;
     auto entry = [&](int f) -> double2 {
         const double2 s = a.tape[size_t(f < 0 ? 0 : f) * sv + boff + xl];

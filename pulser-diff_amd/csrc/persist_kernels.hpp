@@ -143,7 +143,7 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist(P
             auto det_group = [&](int g) {
                 const double c = cf(2 * a.ga + g);
 #pragma unroll
-                for (int r = 0; r < R; ++r) dsh[r] += c * double(a.dcnt[g] - __popc((unsigned(r) * NT + tid) & a.dmask[g]));
+                for (int r = 0; r < R; ++r) dsh[r] += c * double(a.dcnt[g] - popc_i((unsigned(r) * NT + tid) & a.dmask[g]));
             };
             if constexpr (SMALLG) {
 #pragma unroll
@@ -418,7 +418,7 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist_b
                     double d = ud[r];
 #pragma unroll
                     for (int g = 0; g < GL; ++g)
-                        if (g < a.gd) d += cf[2 * a.ga + g] * double(a.dcnt[g] - __popc(x & a.dmask[g]));
+                        if (g < a.gd) d += cf[2 * a.ga + g] * double(a.dcnt[g] - popc_i(x & a.dmask[g]));
                     const double dr = pf.gr + pf.br * d, di = pf.gi + pf.bi * d;
                     q[r].x = dr * v[r].x - di * v[r].y;
                     q[r].y = dr * v[r].y + di * v[r].x;
@@ -511,7 +511,7 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist_b
                     double d = ud[r];
 #pragma unroll
                     for (int g = 0; g < GL; ++g)
-                        if (g < a.gd) d += cf[2 * a.ga + g] * double(a.dcnt[g] - __popc(x & a.dmask[g]));
+                        if (g < a.gd) d += cf[2 * a.ga + g] * double(a.dcnt[g] - popc_i(x & a.dmask[g]));
                     hm[r].x = d * mu[r].x;
                     hm[r].y = d * mu[r].y;
                     const double pr = pf.br * mu[r].x + pf.bi * mu[r].y, pi = pf.bi * mu[r].x - pf.br * mu[r].y;
@@ -519,7 +519,7 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist_b
                     wt[r] += rr;
 #pragma unroll
                     for (int g = 0; g < GL; ++g)
-                        if (g < a.gd) acc_det[g] += rr * double(a.dcnt[g] - __popc(x & a.dmask[g]));
+                        if (g < a.gd) acc_det[g] += rr * double(a.dcnt[g] - popc_i(x & a.dmask[g]));
                 }
 #pragma unroll
                 for (int g = 0; g < GL; ++g) {

@@ -40,6 +40,8 @@ struct Groups {
     uint32_t amp_index_mask[kMaxGroups];  // bits of the AMPLITUDE index (qubit j <-> bit N-1-j)
     uint64_t members[kMaxGroups];         // which terms contribute to this group's coefficient
     int count[kMaxGroups];                // qubits in the group
+    uint32_t flagged = 0;                 // groups whose member terms carry the flag (amp: conditioned flips, det: ones-counting)
+    int nq[kMaxGroups] = {0};             // detuning groups: qubits in the group (count is 0 for a ones-counting group)
 };
 
 struct Plan {
@@ -74,8 +76,9 @@ struct Plan {
 
 inline size_t align_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
 
-inline bool build_groups(int N, int n_terms, const uint32_t* masks, Groups& g, std::string& err) {
+inline bool build_groups(int N, int n_terms, const uint32_t* masks, Groups& g, std::string& err, uint64_t term_flags = 0) {
     g.n = 0;
+    g.flagged = 0;
     if (n_terms > RYDIFF_MAX_TERMS) {
         err = "too many terms (max " + std::to_string(RYDIFF_MAX_TERMS) + ")";
         return false;
@@ -96,6 +99,13 @@ inline bool build_groups(int N, int n_terms, const uint32_t* masks, Groups& g, s
         }
         g.amp_index_mask[found] |= (1u << (N - 1 - j));
         g.count[found] += 1;
+        if (sig & term_flags) {
+            if ((sig & term_flags) != sig) {
+                err = "terms that address qubit " + std::to_string(j) + " disagree on amp_conditioned_terms / det_ones_terms";
+                return false;
+            }
+            g.flagged |= 1u << found;
+        }
     }
     for (int k = 0; k < n_terms; ++k) {
         if (masks[k] == 0 || (N < 32 && (masks[k] >> N) != 0)) {
@@ -234,8 +244,21 @@ inline bool build_plan(const RydProblem* p, Plan& pl, std::string& err, double w
             return false;
         }
     }
-    if (!build_groups(pl.N, pl.Ka, p->amp_masks, pl.ga, err)) return false;
-    if (!build_groups(pl.N, pl.Kd, p->det_masks, pl.gd, err)) return false;
+    if (!build_groups(pl.N, pl.Ka, p->amp_masks, pl.ga, err, p->amp_conditioned_terms)) return false;
+    if (!build_groups(pl.N, pl.Kd, p->det_masks, pl.gd, err, p->det_ones_terms)) return false;
+    if (pl.ga.flagged && (pl.N & 1)) {
+        err = "conditioned flips pair the qubits (2i, 2i+1): n_qubits must be even";
+        return false;
+    }
+    if ((pl.ga.flagged || pl.gd.flagged) && (p->shard_bits || p->n_pair_terms)) {
+        err = "conditioned flips / ones-counting terms: not implemented together with state sharding or pair terms";
+        return false;
+    }
+    // ones-counting detuning groups contribute dcoef * (0 - #ones): the kernels' (count - popcount) with count = 0
+    for (int g = 0; g < pl.gd.n; ++g) {
+        pl.gd.nq[g] = pl.gd.count[g];
+        if (pl.gd.flagged >> g & 1u) pl.gd.count[g] = 0;
+    }
     pl.NC = 2 * pl.ga.n + pl.gd.n;
 
     pl.stages.clear();

@@ -66,12 +66,24 @@ static int fail(int code, const std::string& msg) {
 // ------------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------------
+// HIP's __popc returns UNSIGNED: `count - __popc(x)` with count < popcount (a ones-counting detuning group has count 0) would wrap
+__device__ __forceinline__ int popc_i(uint32_t v) { return int(__popc(v)); }
+
 struct GroupArgs {
     int ga, gd;
     uint32_t amask[kMaxGroups];  // amplitude-index bit masks of the flip groups
     uint32_t dmask[kMaxGroups];  // amplitude-index bit masks of the detuning groups
-    int dcnt[kMaxGroups];        // qubits per detuning group
+    int dcnt[kMaxGroups];        // qubits per detuning group (0: the group counts ones, RydProblem.det_ones_terms)
+    uint32_t cond;               // flip groups whose flips act only where the sibling qubit (index bit ^ 1) is 1 (amp_conditioned_terms)
 };
+
+// conditioned flip of index bit `bit` (one-hot): does it act on amplitude x?  Flip and sibling are different bits, so the partner
+// x ^ bit passes the same test.
+__device__ __forceinline__ bool flip_acts(uint32_t cond_groups, int q, uint32_t x, uint32_t bit) {
+    if (!(cond_groups >> q & 1u)) return true;
+    const uint32_t sib = (bit & 0x55555555u) ? (bit << 1) : (bit >> 1);
+    return (x & sib) != 0u;
+}
 
 // dense two-qubit terms of the generator (include/rydiff.h: pair terms)
 struct PairArgs {
@@ -296,6 +308,7 @@ struct StatsArgs {
     int ga, gd;
     uint64_t amem[kMaxGroups], dmem[kMaxGroups];
     int acnt[kMaxGroups], dcnt[kMaxGroups];
+    uint32_t dones;  // detuning groups that count ones: (count - popcount) ranges over [-dcnt, 0] instead of [0, dcnt]
 };
 
 __global__ void k_table_stats(unsigned long long* __restrict__ stats, StatsArgs a) {
@@ -318,6 +331,7 @@ __global__ void k_table_stats(unsigned long long* __restrict__ stats, StatsArgs 
             double d = 0.0;
             for (int k = 0; k < a.Kd; ++k)
                 if (a.dmem[g] >> k & 1ull) d += 2.0 * a.det[(size_t(b) * a.Kd + k) * a.n_samples + i];
+            if (a.dones >> g & 1u) d = -d;
             if (d > 0.0) dpos += d * a.dcnt[g];
             else dneg += -d * a.dcnt[g];
         }
@@ -408,7 +422,7 @@ __global__ void k_expand_coeffs(ExpandArgs a) {
 __device__ __forceinline__ double diag_value(const double* __restrict__ udiag, const double* __restrict__ cf, const GroupArgs& g,
                                              uint32_t x, uint32_t xglob) {
     double d = udiag[x];
-    for (int q = 0; q < g.gd; ++q) d += cf[2 * g.ga + q] * double(g.dcnt[q] - __popc(xglob & g.dmask[q]));
+    for (int q = 0; q < g.gd; ++q) d += cf[2 * g.ga + q] * double(g.dcnt[q] - popc_i(xglob & g.dmask[q]));
     return d;
 }
 __device__ __forceinline__ double diag_value(const double* __restrict__ udiag, const double* __restrict__ cf, const GroupArgs& g,
@@ -447,6 +461,7 @@ __global__ __launch_bounds__(256) void k_factor_direct(FactorArgs a) {
         while (m) {
             const uint32_t bit = m & (0u - m);
             m ^= bit;
+            if (!flip_acts(a.g.cond, q, x, bit)) continue;
             const double2 p = xin[x ^ bit];
             if (x & bit) {
                 s1r += p.x;
@@ -508,6 +523,7 @@ __global__ __launch_bounds__(256) void k_factor_bwd_direct(FactorBwdArgs a) {
         while (m) {
             const uint32_t bit = m & (0u - m);
             m ^= bit;
+            if (!flip_acts(a.g.cond, q, xs, bit)) continue;
             const double2 p = gin[xs ^ bit];
             const double2 t = xin[xs ^ bit];
             if (xs & bit) {
@@ -534,7 +550,7 @@ __global__ __launch_bounds__(256) void k_factor_bwd_direct(FactorBwdArgs a) {
         block_atomic_add(gim, ge + a.g.ga + q, lds);
     }
     for (int q = 0; q < a.g.gd; ++q) {
-        const double v = live ? r * double(a.g.dcnt[q] - __popc(x & a.g.dmask[q])) : 0.0;
+        const double v = live ? r * double(a.g.dcnt[q] - popc_i(x & a.g.dmask[q])) : 0.0;
         block_atomic_add(v, ge + 2 * a.g.ga + q, lds);
     }
     if (a.pair.n && live) {  // conj(beta) * (pair terms)^dagger applied to the cotangent
@@ -647,7 +663,7 @@ __global__ __launch_bounds__(256) void k_factor_bwd_direct_global(FactorBwdArgs 
     if (a.wtot) unsafeAtomicAdd(a.wtot + x, r);
     // the two drive gradients and the first detuning gradient share ONE workgroup reduction (one pair of barriers)
     double v0 = wave_sum(pr * xsr - pi * xsi), v1 = wave_sum(-(pr * xdi + pi * xdr));
-    double v2 = wave_sum(a.g.gd > 0 ? r * double(a.g.dcnt[0] - __popc(x & a.g.dmask[0])) : 0.0);
+    double v2 = wave_sum(a.g.gd > 0 ? r * double(a.g.dcnt[0] - popc_i(x & a.g.dmask[0])) : 0.0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) {
         lds3[wave] = v0;
@@ -659,7 +675,7 @@ __global__ __launch_bounds__(256) void k_factor_bwd_direct_global(FactorBwdArgs 
         const double sum = lds3[4 * threadIdx.x] + lds3[4 * threadIdx.x + 1] + lds3[4 * threadIdx.x + 2] + lds3[4 * threadIdx.x + 3];
         if (threadIdx.x < 2 || a.g.gd > 0) unsafeAtomicAdd(ge + threadIdx.x, sum);
     }
-    for (int q = 1; q < a.g.gd; ++q) block_atomic_add(r * double(a.g.dcnt[q] - __popc(x & a.g.dmask[q])), ge + 2 + q, lds);
+    for (int q = 1; q < a.g.gd; ++q) block_atomic_add(r * double(a.g.dcnt[q] - popc_i(x & a.g.dmask[q])), ge + 2 + q, lds);
 }
 
 // dL/dtau of one exponential:  Re< g, -i H x >  = Im( sum_x conj(g[x]) (H x)[x] )
@@ -696,6 +712,7 @@ __global__ __launch_bounds__(256) void k_dot_hx(DotHArgs a) {
         while (m) {
             const uint32_t bit = m & (0u - m);
             m ^= bit;
+            if (!flip_acts(a.gr.cond, q, xs, bit)) continue;
             const double2 p = xin[xs ^ bit];
             if (xs & bit) { s1r += p.x; s1i += p.y; } else { s0r += p.x; s0i += p.y; }
         }
@@ -1043,6 +1060,7 @@ void fill_group_args(const Plan& pl, GroupArgs& g) {
         g.dmask[q] = pl.gd.amp_index_mask[q];
         g.dcnt[q] = pl.gd.count[q];
     }
+    g.cond = pl.ga.flagged;
 }
 
 // half width of the generator's numerical range (same widening as finish_runtime)
@@ -1076,6 +1094,10 @@ int finish_runtime(Runtime& rt, double lo, double hi) {
         rt.max_step_factors = std::max(rt.max_step_factors, f);
     }
     fill_group_args(pl, rt.garg);
+    if (pl.ga.flagged) {  // conditioned flips (three-level registers): the generic one-amplitude-per-thread kernels, any size
+        rt.generic_direct = true;
+        rt.variant = 1;
+    }
     rt.parg.n = pl.n_pair;
     for (int t = 0; t < pl.n_pair; ++t) {
         rt.parg.ma[t] = pl.pair_ma[t];
@@ -1102,8 +1124,9 @@ int run_stats(const RydProblem* p, const Plan& pl, void* scratch, hipStream_t st
     }
     for (int g = 0; g < pl.gd.n; ++g) {
         sa.dmem[g] = pl.gd.members[g];
-        sa.dcnt[g] = pl.gd.count[g];
+        sa.dcnt[g] = pl.gd.nq[g];
     }
+    sa.dones = pl.gd.flagged;
     HIP_TRY(hipMemsetAsync(scratch, 0, 8 * sizeof(double), stream));
     const int ns = std::max(pl.n_samples, 1);
     dim3 grid((ns + 127) / 128, pl.Bc);

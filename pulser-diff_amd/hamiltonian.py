@@ -12,7 +12,8 @@ constructor arguments produce the *structure* only:
 
 and the native library applies H(t) to the state without ever materialising it.  ``_hamiltonian(t)`` (used by
 ``TorchEmulator.get_hamiltonian``, ``backend.py:401-427``) still returns an explicit matrix for small registers.
-Only the ground-rydberg ("ising") basis is on the hot path.  Stochastic noise (doppler, amplitude, SPAM;
+The two-level bases (ground-rydberg, digital, XY) share one structure; the three-level basis "all" runs as two qubits per atom
+with conditioned flips (``embedded_three_level``).  Stochastic noise (doppler, amplitude, SPAM;
 ``hamiltonian.py:170-219,270-286``) is a perturbation of the sampled coefficient arrays, i.e. more trajectories of the same
 Schroedinger problem: ``noisy_batch_tables`` draws all realisations at once and returns per-run tables for ONE batched
 call of the native solver.  Noise types with collapse operators (hamiltonian.py:98-143) are kept as single-qubit operators
@@ -99,6 +100,10 @@ class Hamiltonian:
             raise NotImplementedError(f"Noise types {sorted(unknown)} are not implemented in the MI355X-native backend.")
         if not hasattr(self, "basis_name"):
             self._build_basis_and_op_matrices()
+        if self.basis_name == "all" and cfg.noise_types:
+            # hamiltonian.py:98-103 refuses dephasing / depolarizing / eff_noise in the all-basis; the stochastic noises and
+            # relaxation would need the per-qubit tables / the doubled register on the two-qubit-per-atom encoding
+            raise NotImplementedError(f"Cannot include {sorted(cfg.noise_types)[0]} noise in all-basis.")
         self._config = cfg
         if not ("SPAM" in cfg.noise_types and cfg.state_prep_error > 0):
             self._bad_atoms = {qid: False for qid in self._qid_index}
@@ -123,9 +128,12 @@ class Hamiltonian:
             basis = ["g", "h"]
             projectors = ["hg", "hh", "gg"]
         else:
-            raise NotImplementedError("The three-level 'all' basis (ground-rydberg and digital channels in one sequence, "
-                                      "hamiltonian.py:306-310) is not supported by the MI355X-native backend.")
-        self.dim = 2
+            # ground-rydberg AND digital channels in one sequence: three levels per atom (hamiltonian.py:306-310).  The native
+            # solver runs them as TWO qubits per atom (embedded_three_level, below).
+            self.basis_name = "all"
+            basis = ["r", "g", "h"]
+            projectors = ["gr", "hg", "rr", "gg", "hh"]
+        self.dim = len(basis)
         self.basis = {b: basis_state(self.dim, i) for i, b in enumerate(basis)}
         self.op_matrix = {"I": torch.eye(self.dim).to_sparse()}
         for proj in projectors:
@@ -255,34 +263,65 @@ class Hamiltonian:
 
         amp_terms: list[tuple[Tensor, int]] = []
         det_terms: list[tuple[Tensor, int]] = []
+        amp_cond: list[bool] = []   # three-level registers only: RydProblem.amp_conditioned_terms / det_ones_terms
+        det_ones: list[bool] = []
+        self._ref_terms = []        # the reference's own term list (basis, kind, coefficients, atoms): explicit H(t) of the all-basis
 
         phase_free = [True]  # every drive has phase 0 and no gradient is asked for the phase
+        three = self.basis_name == "all"
 
-        def add_terms(samples: dict, mask: int) -> None:
+        def add_terms(samples: dict, atoms: list, basis: str) -> None:
             # hamiltonian.py:420-433 / 439-452
             ph = samples["phase"]
             amp_c = 0.5 * samples["amp"] * torch.exp(-1j * ph.to(CD))
             det_c = -0.5 * samples["det"]
-            if torch.any(amp_c != 0):
-                amp_terms.append((self._adapt_to_sampling_rate(amp_c), mask))
-                if ph.requires_grad or bool(torch.any(ph != 0)):
-                    phase_free[0] = False
-            if torch.any(det_c != 0):
-                det_terms.append((self._adapt_to_sampling_rate(det_c), mask))
+            has_amp, has_det = bool(torch.any(amp_c != 0)), bool(torch.any(det_c != 0))
+            if has_amp and (ph.requires_grad or bool(torch.any(ph != 0))):
+                phase_free[0] = False
+            if not three:
+                mask = sum(1 << j for j in atoms)
+                if has_amp:
+                    amp_terms.append((self._adapt_to_sampling_rate(amp_c), mask))
+                if has_det:
+                    det_terms.append((self._adapt_to_sampling_rate(det_c), mask))
+                return
+            # Two qubits per atom, atom i = qubits (2i, 2i+1) = (a, b): r = (0,1), g = (1,1), h = (1,0) (include/rydiff.h).
+            a_mask, b_mask = sum(1 << (2 * j) for j in atoms), sum(1 << (2 * j + 1) for j in atoms)
+            if has_amp:
+                c = self._adapt_to_sampling_rate(amp_c)
+                self._ref_terms.append((basis, "amp", c, list(atoms)))
+                if basis == "ground-rydberg":   # c |g><r| + h.c.: flip a where b = 1; <a=1| H |a=0> = c as in the two-level basis
+                    amp_terms.append((c, a_mask))
+                else:                           # c |h><g| + h.c.: flip b where a = 1; <b=1| H |b=0> = <g| H |h> = conj(c)
+                    amp_terms.append((torch.conj(c), b_mask))
+                amp_cond.append(True)
+            if has_det:
+                d = self._adapt_to_sampling_rate(det_c)
+                self._ref_terms.append((basis, "det", d, list(atoms)))
+                if basis == "ground-rydberg":   # 2 d sigma_rr = 2 d (1 - a)
+                    det_terms.append((d, a_mask))
+                    det_ones.append(False)
+                else:                           # 2 d sigma_gg (hamiltonian.py:413) = 2 d (a + b - 1) = -2 d (1 - a) + 2 d b on the valid codes
+                    det_terms.append((-d, a_mask))
+                    det_ones.append(False)
+                    det_terms.append((-d, b_mask))  # ones-counting: contributes 2 (-d) (0 - b) = 2 d b
+                    det_ones.append(True)
 
-        all_mask = (1 << n) - 1
         for addr in self.samples:
             for basis in self.samples[addr]:
                 if not self.samples[addr][basis]:
                     continue
-                if basis != self.basis_name:
+                if basis != self.basis_name and not (three and basis in ("ground-rydberg", "digital")):
                     raise NotImplementedError(f"Samples in the {basis!r} basis next to the {self.basis_name!r} basis are not supported.")
                 if addr == "Global":
-                    add_terms(self.samples[addr][basis], all_mask)
+                    add_terms(self.samples[addr][basis], list(range(n)), basis)
                 else:
                     for q_id, samples_q in self.samples[addr][basis].items():
-                        add_terms(samples_q, 1 << self._qid_index[q_id])
+                        add_terms(samples_q, [self._qid_index[q_id]], basis)
         self._amp_terms, self._det_terms = amp_terms, det_terms
+        self._amp_cond, self._det_ones = tuple(amp_cond), tuple(det_ones)
+        if three and phase_free[0]:
+            phase_free[0] = False  # (the conjugated digital tables are kept complex: one code path)
         self.n_samples = int(self._sampling_rate * self._duration)  # hamiltonian.py:524
         self.dt = 0.001 / self._sampling_rate  # hamiltonian.py:523
         ns = self.n_samples
@@ -299,7 +338,14 @@ class Hamiltonian:
     def _rebuild_u_pairs(self) -> None:
         """U_ij = C6 / r_ij^6 from the stored distance tensors (hamiltonian.py:341-344).  The digital basis has no
         interaction term (hamiltonian.py:460) and the XY interaction is not diagonal (pair terms, below): zeros there."""
-        if self.basis_name != "ground-rydberg":
+        if self.basis_name == "all":
+            # qubits (2i, 2i+1) per atom: the van der Waals term couples the a qubits (n_r = 1 - a), every other pair is free
+            n = self._size
+            us = {(2 * i, 2 * j): self._device.interaction_coeff / d**6
+                  for (i, j), d in zip(itertools.combinations(range(n), 2), self._dist_dict.values())}
+            zero = torch.zeros((), dtype=RD)
+            self._u_pairs_host = torch.stack([us.get(pq, zero).reshape(()) for pq in itertools.combinations(range(2 * n), 2)])
+        elif self.basis_name != "ground-rydberg":
             self._u_pairs_host = torch.zeros(len(self._dist_dict), dtype=RD)
         else:
             us = [self._device.interaction_coeff / d**6 for d in self._dist_dict.values()]
@@ -344,8 +390,26 @@ class Hamiltonian:
 
     def problem_spec(self, solver: SolverType = SolverType.KRYLOV_SE, tol: float = 0.0,
                      store_states: bool = True) -> ProblemSpec:
-        return ProblemSpec(self._size, self.dt, self.n_samples, self.amp_masks, self.det_masks, solver=solver, tol=tol,
-                           store_states=store_states, pair_terms=tuple(getattr(self, "pair_terms", ())))
+        return ProblemSpec(self.n_solver_qubits, self.dt, self.n_samples, self.amp_masks, self.det_masks, solver=solver, tol=tol,
+                           store_states=store_states, pair_terms=tuple(getattr(self, "pair_terms", ())),
+                           amp_conditioned=self._amp_cond, det_ones=self._det_ones)
+
+    # ---- three-level registers on the two-level solver ------------------------------------------------------------------
+    @property
+    def n_solver_qubits(self) -> int:
+        return 2 * self._size if self.basis_name == "all" else self._size
+
+    def embedded_three_level(self) -> Tensor:
+        """Index of every three-level basis state (digits r = 0, g = 1, h = 2, atom 0 most significant: the reference's kron order)
+        in the 4^n-amplitude vector of the two-qubit-per-atom encoding (codes r = 01, g = 11, h = 10; 00 is never populated)."""
+        if getattr(self, "_embed_index", None) is None:
+            n = self._size
+            idx = torch.zeros(1, dtype=torch.long)
+            code = torch.tensor([1, 3, 2], dtype=torch.long)
+            for _ in range(n):
+                idx = (idx[:, None] * 4 + code[None, :]).reshape(-1)
+            self._embed_index = idx
+        return self._embed_index
 
     # ------------------------------------------------------------------------------------------------------
     def _interp(self, coeff: Tensor, t: Tensor) -> Tensor:
@@ -358,6 +422,26 @@ class Hamiltonian:
     def build_ham_tensor(self) -> Callable[[Union[float, Tensor]], Tensor]:
         """hamiltonian.py:499-548: returns H_t(t) -> explicit sparse COO matrix (small registers; for inspection)."""
         n = self._size
+
+        def H_t_three_level(t: Union[float, Tensor]) -> Tensor:
+            """hamiltonian.py:526-546 with the reference's own operators (sigma_gr / sigma_rr, sigma_hg / sigma_gg)."""
+            if n > 8:
+                raise ValueError("get_hamiltonian builds an explicit 3^n matrix and is limited to 8 atoms in the all-basis.")
+            if not isinstance(t, Tensor):
+                t = torch.tensor(t, dtype=RD)
+            ids = list(self._qdict)
+            ham = torch.zeros(3**n, 3**n, dtype=CD)
+            for (i, j), d in zip(itertools.combinations(range(n), 2), self._dist_dict.values()):
+                ham = ham + (self._device.interaction_coeff / d.detach() ** 6) * self.build_operator([("sigma_rr", [ids[i], ids[j]])]).to_dense().to(CD)
+            op_ids = {("ground-rydberg", "amp"): "sigma_gr", ("ground-rydberg", "det"): "sigma_rr",
+                      ("digital", "amp"): "sigma_hg", ("digital", "det"): "sigma_gg"}
+            for basis, kind, coeff, atoms in self._ref_terms:
+                m = sum(self.build_operator([(op_ids[(basis, kind)], [ids[a]])]).to_dense().to(CD) for a in atoms) * self._interp(coeff.detach().to(CD), t)
+                ham = ham + m + m.mH
+            return ham.to_sparse().coalesce()
+
+        if self.basis_name == "all":
+            return H_t_three_level
 
         def H_t(t: Union[float, Tensor]) -> Tensor:
             if n > MAX_EXPLICIT_QUBITS:

@@ -32,10 +32,13 @@ class TorchResult:
 
     @property
     def _dim(self) -> int:
-        return 2
+        """result.py:53-58: levels per atom, from the size of the state."""
+        return int(round(self.state.shape[0] ** (1.0 / max(self._size, 1))))  # kets (dim, B) and density matrices (dim, dim[, B]) alike
 
     @property
     def _basis_name(self) -> str:
+        if self._dim > 2:
+            return "all"
         if not self.matching_meas_basis:
             return "digital" if self.meas_basis == "ground-rydberg" else "ground-rydberg"
         return self.meas_basis
@@ -47,7 +50,22 @@ class TorchResult:
             probs = torch.abs(torch.diagonal(st[..., 0] if st.ndim == 3 else st)).flatten().cpu()
         else:
             probs = (torch.abs(st[:, 0]) ** 2).flatten().cpu()
-        if self.matching_meas_basis:
+        if self._dim == 3:
+            # result.py:86-110: three levels (r, g, h); a measurement in the ground-rydberg basis reads 1 for r, in the digital
+            # basis 1 for h, and 0 for the other two levels: marginalise every atom's axis with a 2 x 3 table
+            if self.meas_basis not in ("ground-rydberg", "digital"):
+                raise RuntimeError(f"Unknown measurement basis '{self.meas_basis}' for a three-level system.'")
+            one = 0 if self.meas_basis == "ground-rydberg" else 2
+            table = torch.ones(2, 3, dtype=probs.dtype)
+            table[0, one] = 0.0
+            table[1] = 0.0
+            table[1, one] = 1.0
+            n = self._size
+            w = probs.reshape([3] * n)
+            for axis in range(n):  # contract axis `axis` (3 levels) into the outcome bit of that atom
+                w = torch.movedim(torch.tensordot(w, table, dims=([axis], [1])), -1, axis)
+            weights = w.reshape(-1)
+        elif self.matching_meas_basis:
             # state ordered with r first ([rr, rg, gr, gg] -> [11, 10, 01, 00]); invert to [00, 01, 10, 11]
             weights = probs.flip(0) if self.meas_basis == "ground-rydberg" else probs
         else:

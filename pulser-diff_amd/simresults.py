@@ -56,7 +56,10 @@ class CoherentResults(SimulationResults, collections.abc.Sequence):
                  native_expect: Optional[Tensor] = None, native_observables: Optional[list] = None,
                  stats: Optional[dict] = None, density: bool = False) -> None:
         super().__init__(size, basis_name, sim_times)
-        if meas_basis != self._basis_name:
+        if self._basis_name == "all":  # simresults.py:381-383
+            if meas_basis not in {"ground-rydberg", "digital"}:
+                raise ValueError("`meas_basis` must be 'ground-rydberg' or 'digital'.")
+        elif meas_basis != self._basis_name:
             raise ValueError("`meas_basis` and `basis_name` must have the same value.")
         if meas_errors is not None and not {"epsilon", "epsilon_prime"} <= set(meas_errors.keys()):
             raise ValueError("Measurement error probabilities must be given in the form `{'epsilon':0.01, 'epsilon_prime':0.05}`")

@@ -55,6 +55,9 @@ class ProblemSpec:
     pair_terms: tuple = ()
     # kernel family (RydProblem.kernel_variant): None = this thread's default (_native.set_kernel_variant, normally 0 = automatic)
     kernel_variant: Optional[int] = None
+    # three-level registers as two qubits per atom (include/rydiff.h, amp_conditioned_terms / det_ones_terms): per-term flags
+    amp_conditioned: tuple = ()   # () or one bool per amplitude term: the flip acts only where the sibling qubit (j ^ 1) is 1
+    det_ones: tuple = ()          # () or one bool per detuning term: the term counts the ones of its mask with minus its coefficient
 
     def solver_code(self) -> int:
         if self.solver not in _SOLVER_CODE:
@@ -129,6 +132,8 @@ class _Call:
         p.pair_tables = self.pair_tables.ctypes.data if spec.pair_terms else None
         p.real_amp_grad = int(real_amp_grad)  # the caller's amplitude tables are a REAL tensor: only Re(g_amp) is used
         p.kernel_variant = _native.default_kernel_variant() if spec.kernel_variant is None else int(spec.kernel_variant)
+        p.amp_conditioned_terms = sum(1 << k for k, f in enumerate(spec.amp_conditioned) if f)
+        p.det_ones_terms = sum(1 << k for k, f in enumerate(spec.det_ones) if f)
         self.problem = p
 
 
@@ -136,6 +141,8 @@ def _check_shapes(spec: ProblemSpec, amp: Tensor, det: Tensor, u_pairs: Tensor, 
     """The C ABI sees raw pointers only: every buffer is checked against the spec here, so that a mismatch is a ValueError and
     never an out-of-bounds device read."""
     ka, kd, n, nq = len(spec.amp_masks), len(spec.det_masks), spec.n_samples, spec.n_qubits
+    if len(spec.amp_conditioned) not in (0, ka) or len(spec.det_ones) not in (0, kd):
+        raise ValueError("amp_conditioned / det_ones: one flag per amplitude / detuning term (or empty)")
     cb = None
     for name, t, k in (("amp_tables", amp, ka), ("det_tables", det, kd)):
         if k == 0:
@@ -319,6 +326,18 @@ def sesolve(problem, psi0: Tensor, tsave: Tensor, solver: SolverType = SolverTyp
     spec = problem.problem_spec(solver=solver, tol=tolerance_from_options(options), store_states=store_states)
     psi_bd = psi0.reshape(psi0.shape[0], -1).transpose(0, 1)
     amp_tables = problem.amp_tables.real if getattr(problem, "amp_is_real", False) else problem.amp_tables
+    embed = None
+    if getattr(problem, "basis_name", None) == "all":
+        # three levels per atom = two qubits per atom: scatter the 3^n amplitudes (and diagonal observables) into the 4^n
+        # vector, gather the states back; the unused codes carry exact zeros (nothing couples to them)
+        embed = problem.embedded_three_level().to(psi_bd.device)
+        big = torch.zeros(psi_bd.shape[0], 1 << spec.n_qubits, dtype=psi_bd.dtype, device=psi_bd.device)
+        psi_bd = big.index_copy(1, embed, psi_bd)
+        if obs_diag is not None:
+            obs_diag = torch.zeros(obs_diag.shape[0], 1 << spec.n_qubits, dtype=obs_diag.dtype,
+                                   device=obs_diag.device).index_copy(1, embed, obs_diag)
     states, expect = evolve(amp_tables, problem.det_tables, problem.u_pairs, tsave, psi_bd, spec, obs_diag)
+    if embed is not None and states.numel():
+        states = states.index_select(2, embed)
     return SolveResult(states.permute(0, 2, 1) if states.numel() else states, expect,
                        dict(spec.options.get("_last_stats", {})))

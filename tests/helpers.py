@@ -111,3 +111,37 @@ def unpack_terms(d) -> R.HamTerms:
     t.extra_amp = [(torch.as_tensor(c), targets(m)) for c, m in zip(d["amp_tables"], d["amp_masks"])]
     t.extra_det = [(torch.as_tensor(c), targets(m)) for c, m in zip(d["det_tables"], d["det_masks"])]
     return t
+
+
+def dense_from_structured_terms(n_qubits, u_pairs, amp_terms, det_terms, amp_conditioned=(), det_ones=()):
+    """The C ABI's term semantics (include/rydiff.h) as an explicit 2^N x 2^N matrix, for small N: test infrastructure.
+      amp term (c, mask):  <bit_j = 1| H |bit_j = 0> = c, <0|H|1> = conj(c) for every qubit j of the mask; a CONDITIONED term acts
+                           only where the sibling qubit j ^ 1 is 1;
+      det term (d, mask):  2 d * (#zeros of the mask), a ONES-counting term 2 d * (0 - #ones);
+      u_pairs:             U_ij on (1 - bit_i)(1 - bit_j), itertools.combinations order.  Qubit j = index bit N-1-j."""
+    import itertools
+
+    dim = 2**n_qubits
+    x = torch.arange(dim)
+    bit = lambda j: (x >> (n_qubits - 1 - j)) & 1  # noqa: E731
+    diag = torch.zeros(dim, dtype=torch.complex128)
+    for k, (i, j) in enumerate(itertools.combinations(range(n_qubits), 2)):
+        diag = diag + u_pairs[k] * ((1 - bit(i)) * (1 - bit(j)))
+    for k, (d, mask) in enumerate(det_terms):
+        ones = bool(det_ones[k]) if det_ones else False
+        for j in range(n_qubits):
+            if mask >> j & 1:
+                diag = diag + 2.0 * d * ((0 - bit(j)) if ones else (1 - bit(j)))
+    h = torch.diag(diag)
+    for k, (c, mask) in enumerate(amp_terms):
+        cond = bool(amp_conditioned[k]) if amp_conditioned else False
+        for j in range(n_qubits):
+            if not (mask >> j & 1):
+                continue
+            m = 1 << (n_qubits - 1 - j)
+            rows = x[(x & m) != 0]
+            if cond:
+                rows = rows[((rows >> (n_qubits - 1 - (j ^ 1))) & 1) == 1]
+            h[rows, rows ^ m] += c
+            h[rows ^ m, rows] += complex(c).conjugate() if not isinstance(c, torch.Tensor) else torch.conj(c)
+    return h

@@ -1,0 +1,182 @@
+"""The reference's three-level basis "all" (a ground-rydberg and a digital channel in one sequence, hamiltonian.py:306-310) on the
+native solver: two qubits per atom, conditioned flips, a ones-counting detuning term (include/rydiff.h, amp_conditioned_terms /
+det_ones_terms).  Reference values: the oracle's literal dense restatement of the reference's three-level operators
+(oracle/restatement.py:reference_style_dense_H_t_three_level) evolved with the KRYLOV_SE map / DOP853, and torch autograd through it."""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import restatement as R
+from tests.helpers import dense_from_structured_terms, rel_err
+from tests.test_host_logic import _three_level_emulator
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n_qubits,batch", [(4, 1), (6, 3), (14, 1)])
+def test_conditioned_flips_and_ones_counting_terms_through_the_c_abi(cuda_device, n_qubits, batch):
+    """Random structured problems with the two new term flags straight through `evolve`: states, <O>(t) and all five gradient kinds
+    against the explicit matrix of the SAME term list (tests/helpers.py:dense_from_structured_terms) under the KRYLOV_SE map.
+    14 qubits: forward only, against the native run of the equivalent problem restricted ... (dense 2^14 is out of reach) — there the
+    check is norm conservation and that the unused codes stay empty."""
+    from pulser_diff_amd.solver import ProblemSpec, SolverType, evolve
+
+    gen = torch.Generator().manual_seed(77 + n_qubits)
+    ns, dt = 7, 0.004
+    n_atoms = n_qubits // 2
+    a_mask, b_mask = sum(1 << (2 * i) for i in range(n_atoms)), sum(1 << (2 * i + 1) for i in range(n_atoms))
+    amp_masks, amp_cond = (a_mask, 1 << 1, b_mask & ~(1 << 1)), (True, True, True)
+    det_masks, det_ones = (a_mask, b_mask, 1 << 0), (False, True, False)
+    amp = (torch.randn(1, 3, ns, generator=gen, dtype=torch.complex128) * 3.0).to(cuda_device)
+    det = (torch.randn(1, 3, ns, generator=gen, dtype=torch.float64) * 2.0).to(cuda_device)
+    pairs = list(itertools.combinations(range(n_qubits), 2))
+    u = torch.tensor([float(5.0 + 7.0 * torch.rand(1, generator=gen)) if (i % 2 == 0 and j % 2 == 0) else 0.0 for i, j in pairs],
+                     dtype=torch.float64).to(cuda_device)
+    tsave = torch.tensor([0.0, 0.004, 0.0095, 0.013, 0.0211], dtype=torch.float64)
+    # start inside the valid subspace (codes 01, 11, 10 per atom)
+    valid = torch.tensor([x for x in range(2**n_qubits) if all(((x >> (2 * k)) & 3) != 0 for k in range(n_atoms))])
+    psi = torch.zeros(batch, 2**n_qubits, dtype=torch.complex128)
+    psi[:, valid] = torch.randn(batch, len(valid), generator=gen, dtype=torch.complex128)
+    psi = (psi / psi.norm(dim=1, keepdim=True)).to(cuda_device)
+    obs = torch.rand(1, 2**n_qubits, generator=gen, dtype=torch.float64).to(cuda_device)
+    spec = ProblemSpec(n_qubits, dt, ns, amp_masks, det_masks, solver=SolverType.KRYLOV_SE, store_states=True,
+                       amp_conditioned=amp_cond, det_ones=det_ones)
+    if n_qubits > 8:
+        with torch.no_grad():
+            states, expect = evolve(amp, det, u, tsave, psi, spec, obs)
+        assert dict(spec.options["_last_stats"])["kernel_family"] == "direct"
+        assert (states.abs().square().sum(-1) - 1).abs().max() < 1e-11
+        invalid = torch.ones(2**n_qubits, dtype=torch.bool)
+        invalid[valid] = False
+        assert states[..., invalid.to(cuda_device)].abs().max() == 0.0
+        return
+    leaves = [amp.clone().requires_grad_(True), det.clone().requires_grad_(True), u.clone().requires_grad_(True),
+              tsave.clone().requires_grad_(True), psi.clone().requires_grad_(True)]
+    states, expect = evolve(*leaves, spec, obs)
+    w = torch.linspace(0.4, 1.3, len(tsave), dtype=torch.float64, device=cuda_device)
+    loss = (expect[0] * w[:, None]).sum() + (states[-1, :, 3].real * 0.7).sum()
+    loss.backward()
+    assert dict(spec.options["_last_stats"])["kernel_family"] == "direct"
+
+    # reference: dense matrix of the same term list, KRYLOV_SE map (right-endpoint H), torch autograd
+    ref_leaves = [t.detach().cpu().clone().requires_grad_(True) for t in leaves]
+    r_amp, r_det, r_u, r_ts, r_psi = ref_leaves
+
+    def interp(tab, t):
+        i1 = max(int(min(np.floor(float(t) / dt), ns - 2)), 0)
+        i2 = min(i1 + 1, ns - 2)
+        return tab[..., i1] + (tab[..., i2] - tab[..., i1]) * (t - i1 * dt) / dt
+
+    def H_t(t):
+        a, d = interp(r_amp[0], t), interp(r_det[0], t)
+        return dense_from_structured_terms(n_qubits, r_u, [(a[k], amp_masks[k]) for k in range(3)],
+                                           [(d[k], det_masks[k]) for k in range(3)], amp_cond, det_ones)
+
+    ref_states = R.krylov_map_from_dense_H(H_t, r_psi.T, r_ts)  # (n_t, dim, B)
+    ref_expect = (ref_states.abs() ** 2 * obs.cpu()[0][None, :, None]).sum(1)
+    ref_loss = (ref_expect * w.cpu()[:, None]).sum() + (ref_states[-1, 3, :].real * 0.7).sum()
+    ref_loss.backward()
+    assert rel_err(states.detach().cpu().permute(0, 2, 1).numpy(), ref_states.detach().numpy()) < 1e-9
+    assert rel_err(expect[0].detach().cpu().numpy(), ref_expect.detach().numpy()) < 1e-9
+    for name, got, ref in zip(("amp", "det", "u", "tsave", "psi0"), leaves, ref_leaves):
+        assert rel_err(got.grad.detach().cpu().numpy(), ref.grad.numpy()) < 1e-8, name
+
+
+@pytest.mark.parametrize("solver_name", ["KRYLOV_SE", "DP5_SE"])
+@pytest.mark.parametrize("local_raman", [True, False])
+def test_three_level_sequence_through_the_emulator(cuda_device, solver_name, local_raman):
+    """A Rydberg and a Raman channel in one sequence through TorchEmulator.run: every stored state (3^n amplitudes, the reference's
+    (r, g, h) order) against the oracle's three-level restatement; KRYLOV_SE = right-endpoint map, DP5_SE = continuous solution."""
+    from pulser_diff_amd.solver import SolverType
+
+    sim, coords = _three_level_emulator(compute_device="cuda", local_raman=local_raman)
+    ham = sim._hamiltonian
+    res = sim.run(solver=getattr(SolverType, solver_name))
+    assert res.solver_stats["kernel_family"] == "direct"
+    states = res.states.detach().cpu()  # (n_t, 27, 1)
+    assert states.shape[1:] == (27, 1)
+    assert (states.abs().square().sum(1) - 1).abs().max() < 1e-10
+    H_ref = R.reference_style_dense_H_t_three_level(coords, [(b, k, c.cpu(), a) for b, k, c, a in ham._ref_terms], ham.dt, ham.n_samples)
+    ts = sim.evaluation_times.detach().cpu()
+    psi0 = sim.initial_state.to(torch.complex128)
+    if solver_name == "KRYLOV_SE":
+        ref = R.krylov_map_from_dense_H(H_ref, psi0, ts)
+        assert (states - ref).abs().max() < 1e-10
+    else:
+        from scipy.integrate import solve_ivp
+
+        sol = solve_ivp(lambda t, y: (-1j * (H_ref(t) @ torch.from_numpy(y))).numpy(), (0.0, float(ts[-1])), psi0[:, 0].numpy(),
+                        method="DOP853", t_eval=ts.numpy(), rtol=1e-12, atol=1e-14, max_step=ham.dt)
+        cont = torch.from_numpy(sol.y.T)
+        # 6.5 um between the first two atoms: U = 72 rad/us, |rrr> at 150 rad/us — beyond the range the default sub-step of the
+        # commutator-free Magnus scheme is calibrated on (csrc/plan.hpp): 7e-8 there, and it converges with `tol` (error ~ h^4)
+        assert (states[:, :, 0] - cont).abs().max() < 2e-7
+        tight = sim.run(solver=SolverType.DP5_SE, tol=1e-12).states.detach().cpu()
+        assert (tight[:, :, 0] - cont).abs().max() < 2e-9
+    # populations move out of |ggg> into both other levels
+    p = states[-1, :, 0].abs().square().reshape(3, 3, 3)
+    assert float(p.sum((1, 2))[0]) > 1e-3 and float(p.sum((0, 2))[2]) > 1e-3
+    # sampling in both measurement bases: ground-rydberg reads r, digital reads h (simresults.py:381-383, result.py:86-110)
+    assert sim._meas_basis == "digital"
+    counts = res.sample_final_state(200)
+    assert sum(counts.values()) == 200 and all(len(k) == 3 for k in counts)
+    obs = torch.diag(torch.arange(27, dtype=torch.float64)).to(torch.complex128)
+    ev = res.expect([obs])[0]
+    assert (ev.cpu() - (states.abs().square()[:, :, 0] * torch.arange(27)).sum(1)).abs().max() < 1e-9
+
+
+def test_three_level_gradients_wrt_pulse_parameters_and_distances(cuda_device):
+    """Autograd from a loss on the three-level final state back to pulse parameters of BOTH channels and to an atom position
+    (dist_grad), against torch autograd through the oracle's dense three-level map."""
+    import pulser_diff_amd as P
+    from pulser_diff_amd import pulses as pl
+    from pulser_diff_amd.solver import SolverType
+
+    def build(omega_r, delta_h, phase_h, q0, module):
+        coords = [q0, torch.tensor([6.5, 1.0], dtype=torch.float64), torch.tensor([2.0, 7.0], dtype=torch.float64)]
+        if module == "product":
+            seq = pl.Sequence(pl.Register({f"q{i}": c for i, c in enumerate(coords)}), pl.MockDevice)
+            seq.declare_channel("ryd", "rydberg_global")
+            seq.declare_channel("ram", "raman_global")
+            seq.add(pl.Pulse.ConstantPulse(120, omega_r, -1.0, 0.2), "ryd")
+            seq.add(pl.Pulse.ConstantPulse(100, 2.5, delta_h, phase_h), "ram")
+            return seq
+        return coords
+
+    leaves = [torch.tensor(4.0, dtype=torch.float64, requires_grad=True), torch.tensor(1.3, dtype=torch.float64, requires_grad=True),
+              torch.tensor(0.4, dtype=torch.float64, requires_grad=True), torch.tensor([0.0, 0.0], dtype=torch.float64, requires_grad=True)]
+    target = torch.randn(27, generator=torch.Generator().manual_seed(5), dtype=torch.complex128)
+    target = target / target.norm()
+    sim = P.TorchEmulator.from_sequence(build(*leaves, "product"), sampling_rate=0.5, compute_device="cuda")
+    res = sim.run(solver=SolverType.KRYLOV_SE, dist_grad=True)
+    final = res.states[-1, :, 0]
+    loss = (target.to(final.device).conj() * final).sum().abs() ** 2
+    loss.backward()
+    got = [l.grad.clone() for l in leaves]
+
+    ref_leaves = [l.detach().clone().requires_grad_(True) for l in leaves]
+    o_r, d_h, p_h, q0 = ref_leaves
+    coords = torch.stack(build(o_r, d_h, p_h, q0, "oracle"))
+    ham = sim._hamiltonian
+    n_full = 121  # 120 ns + the padded sample (backend.py:115)
+    amp_r = torch.cat([o_r.expand(120), torch.zeros(1, dtype=torch.float64)])
+    det_r = torch.cat([torch.full((120,), -1.0, dtype=torch.float64), torch.zeros(1, dtype=torch.float64)])
+    amp_h = torch.cat([torch.full((100,), 2.5, dtype=torch.float64), torch.zeros(21, dtype=torch.float64)])
+    det_h = torch.cat([d_h.expand(100), torch.zeros(21, dtype=torch.float64)])
+    ph_h = torch.cat([p_h.expand(100), p_h.detach().expand(21)])
+    adapt = lambda v: R.adapt_to_sampling_rate(v, 0.5, n_full)  # noqa: E731
+    terms = [("ground-rydberg", "amp", adapt(0.5 * amp_r * torch.exp(-1j * torch.full((n_full,), 0.2, dtype=torch.complex128))), [0, 1, 2]),
+             ("ground-rydberg", "det", adapt(-0.5 * det_r), [0, 1, 2]),
+             ("digital", "amp", adapt(0.5 * amp_h * torch.exp(-1j * ph_h.to(torch.complex128))), [0, 1, 2]),
+             ("digital", "det", adapt(-0.5 * det_h), [0, 1, 2])]
+    assert ham.n_samples == 60 and len(terms[0][2]) == 60
+    H_ref = R.reference_style_dense_H_t_three_level(coords, terms, ham.dt, ham.n_samples)
+    ref_final = R.krylov_map_from_dense_H(H_ref, sim.initial_state.to(torch.complex128), sim.evaluation_times.detach().cpu())[-1, :, 0]
+    ref_loss = (target.conj() * ref_final).sum().abs() ** 2
+    ref_loss.backward()
+    assert abs(float(loss) - float(ref_loss)) < 1e-10
+    for name, g, r in zip(("omega_r", "delta_h", "phase_h", "q0"), got, ref_leaves):
+        assert r.grad.abs().max() > 1e-6, name
+        assert (g.cpu() - r.grad).abs().max() < 1e-8 * max(1.0, float(r.grad.abs().max())), name

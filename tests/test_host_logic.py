@@ -423,3 +423,80 @@ def test_virtual_device_channels_and_limits():
     seq.add(pl.Pulse.ConstantPulse(100, seq.declare_variable("omega"), 0.0, 0.0), "ch")  # parametrised: checked by the user's constraints
     built = seq.build(omega=torch.tensor(3.0))
     assert built.get_duration() == 200 and not built.is_parametrized()
+
+
+def _three_level_emulator(compute_device="cpu", n=3, local_raman=True):
+    """A ground-rydberg AND a digital channel in one sequence: the reference's basis "all" (hamiltonian.py:306-310)."""
+    coords = [[0.0, 0.0], [6.5, 1.0], [2.0, 7.0], [9.0, 6.0]][:n]
+    seq = pl.Sequence(pl.Register.from_coordinates(coords), pl.MockDevice)
+    seq.declare_channel("ryd", "rydberg_global")
+    seq.declare_channel("ram", "raman_local" if local_raman else "raman_global", initial_target="q1" if local_raman else None)
+    seq.add(pl.Pulse(pl.BlackmanWaveform(120, 2.1), pl.RampWaveform(120, -4.0, 3.0), 0.4), "ryd")
+    seq.add(pl.Pulse.ConstantPulse(150, 2.0, -1.5, 0.3), "ram")
+    seq.add(pl.Pulse.ConstantPulse(80, 3.0, 1.5, -0.2), "ryd")
+    if local_raman and n > 2:
+        seq.target("q2", "ram")
+        seq.add(pl.Pulse.ConstantPulse(60, 1.2, 0.7, 0.0), "ram")
+    return P.TorchEmulator.from_sequence(seq, sampling_rate=0.5, compute_device=compute_device), torch.tensor(coords, dtype=torch.float64)
+
+
+@pytest.mark.parametrize("local_raman", [True, False])
+def test_three_level_basis_structure_matches_the_literal_restatement(local_raman):
+    """Basis "all": (i) the explicit 3^n matrix get_hamiltonian returns = the oracle's literal restatement of the reference's
+    operators (sigma_gr / sigma_rr for the Rydberg channel, sigma_hg / sigma_gg for the Raman channel, van der Waals on sigma_rr);
+    (ii) the STRUCTURED problem handed to the native solver — two qubits per atom, conditioned flips, a ones-counting detuning
+    term (include/rydiff.h) — written out as a 4^n matrix: its block on the three valid codes per atom is that same matrix and it
+    does not couple the valid codes to the unused one."""
+    from tests.helpers import dense_from_structured_terms
+
+    sim, coords = _three_level_emulator(local_raman=local_raman)
+    ham = sim._hamiltonian
+    n = ham._size
+    assert sim.basis_name == "all" and list(sim.basis) == ["r", "g", "h"] and sim.dim == 3 and sim._meas_basis == "digital"
+    assert sim.initial_state.shape == (3**n, 1) and sim.initial_state[sum(3**k for k in range(n)), 0] == 1.0  # |g g g>
+    H_ref = R.reference_style_dense_H_t_three_level(coords, ham._ref_terms, ham.dt, ham.n_samples)
+    spec = ham.problem_spec()
+    assert spec.n_qubits == 2 * n and all(spec.amp_conditioned) and any(spec.det_ones) and not all(spec.det_ones)
+    embed = ham.embedded_three_level()
+    assert embed.shape == (3**n,) and len(set(embed.tolist())) == 3**n
+    invalid = torch.tensor(sorted(set(range(4**n)) - set(embed.tolist())))
+    for t_ns in (0, 37, 120, 150, 180, 199):
+        ref = H_ref(t_ns / 1000)
+        got = sim.get_hamiltonian(t_ns).to_dense()
+        assert (got - ref).abs().max() < 1e-12
+        t = torch.tensor(t_ns / 1000, dtype=torch.float64)
+        amp_terms = [(ham._interp(c, t), m) for c, m in zip(ham.amp_tables[0], ham.amp_masks)]
+        det_terms = [(ham._interp(c, t), m) for c, m in zip(ham.det_tables[0], ham.det_masks)]
+        big = dense_from_structured_terms(2 * n, ham.u_pairs, amp_terms, det_terms, spec.amp_conditioned, spec.det_ones)
+        assert (big[embed][:, embed] - ref).abs().max() < 1e-12
+        assert big[embed][:, invalid].abs().max() == 0.0 and big[invalid][:, embed].abs().max() == 0.0
+    assert (ref - ref.mH).abs().max() < 1e-14 and ref.abs().max() > 1.0
+
+
+def test_three_level_basis_refuses_noise_and_the_master_equation():
+    sim, _ = _three_level_emulator()
+    with pytest.raises(NotImplementedError, match="all-basis"):
+        sim.set_config(P.SimConfig(noise="dephasing"))
+    with pytest.raises(NotImplementedError, match="all-basis"):
+        sim.set_config(P.SimConfig(noise="doppler"))
+
+
+def test_three_level_measurement_weights():
+    """result.py:86-110: a three-level state measured in the ground-rydberg basis reads 1 for r, in the digital basis 1 for h."""
+    from pulser_diff_amd.result import TorchResult
+
+    gen = torch.Generator().manual_seed(3)
+    psi = torch.randn(27, 1, generator=gen, dtype=torch.complex128)
+    psi = psi / psi.norm()
+    p = (psi.abs() ** 2).reshape(3, 3, 3)
+    for meas, one in (("ground-rydberg", 0), ("digital", 2)):
+        res = TorchResult(("q0", "q1", "q2"), meas, psi, False)
+        assert res._dim == 3 and res._basis_name == "all"
+        w = res._weights()
+        ref = torch.zeros(8, dtype=torch.float64)
+        for i in range(3):
+            for j in range(3):
+                for k in range(3):
+                    ref[4 * (i == one) + 2 * (j == one) + (k == one)] += p[i, j, k]
+        assert (w - ref).abs().max() < 1e-15 and abs(float(w.sum()) - 1) < 1e-14
+        assert set(res.get_samples(50)) <= {format(i, "03b") for i in range(8)}
