@@ -517,19 +517,17 @@ __global__ __launch_bounds__(256) void k_factor_bwd_direct(FactorBwdArgs a) {
     const double r = pr * xi.x - pi * xi.y;  // Re(beta conj(gy) xi)
     if (a.wtot && live) unsafeAtomicAdd(a.wtot + x, r);
     for (int q = 0; q < a.g.ga; ++q) {
-        double s1r = 0.0, s1i = 0.0, s0r = 0.0, s0i = 0.0;  // partner sums of gin (for the matvec)
-        double t1r = 0.0, t1i = 0.0, t0r = 0.0, t0i = 0.0;  // partner sums of xin (for the contraction)
+        double s1r = 0.0, s1i = 0.0, s0r = 0.0, s0i = 0.0;  // partner sums of gin: for the matvec AND for the contraction
         uint32_t m = a.g.amask[q];
         while (m) {
             const uint32_t bit = m & (0u - m);
             m ^= bit;
             if (!flip_acts(a.g.cond, q, xs, bit)) continue;
             const double2 p = gin[xs ^ bit];
-            const double2 t = xin[xs ^ bit];
             if (xs & bit) {
-                s1r += p.x; s1i += p.y; t1r += t.x; t1i += t.y;
+                s1r += p.x; s1i += p.y;
             } else {
-                s0r += p.x; s0i += p.y; t0r += t.x; t0i += t.y;
+                s0r += p.x; s0i += p.y;
             }
         }
         const double cr = cf[q], ci = cf[a.g.ga + q];
@@ -538,11 +536,16 @@ __global__ __launch_bounds__(256) void k_factor_bwd_direct(FactorBwdArgs a) {
         const double b0r = a.br * cr - a.bi * ci, b0i = -a.br * ci - a.bi * cr;
         ar += b1r * s1r - b1i * s1i + b0r * s0r - b0i * s0i;
         ai += b1r * s1i + b1i * s1r + b0r * s0i + b0i * s0r;
-        // S1 = a_*t1, S0 = a_*t0 ; g_cre = Re(S1+S0), g_cim = -Im(S1-S0)
+        // S1 = sum_x a_(x) t1(x), S0 = sum_x a_(x) t0(x) with t1 / t0 the partner sums of xin over the bits that are 1 / 0 in x;
+        // g_cre = Re(S1+S0), g_cim = -Im(S1-S0).  Re-indexed over the partner (the flip is an involution that toggles the bit):
+        // S1 = sum_y xin(y) beta conj(s0(y)), S0 = sum_y xin(y) beta conj(s1(y)) — the cotangent's partner sums, which the matvec
+        // needs anyway, and the OWN tape element only: no partner loads of the tape vector.
         double gre = 0.0, gim = 0.0;
         if (live) {
-            const double S1r = pr * t1r - pi * t1i, S1i = pr * t1i + pi * t1r;
-            const double S0r = pr * t0r - pi * t0i, S0i = pr * t0i + pi * t0r;
+            const double q0r = a.br * s0r + a.bi * s0i, q0i = a.bi * s0r - a.br * s0i;  // beta conj(s0)
+            const double q1r = a.br * s1r + a.bi * s1i, q1i = a.bi * s1r - a.br * s1i;  // beta conj(s1)
+            const double S1r = q0r * xi.x - q0i * xi.y, S1i = q0r * xi.y + q0i * xi.x;
+            const double S0r = q1r * xi.x - q1i * xi.y, S0i = q1r * xi.y + q1i * xi.x;
             gre = S1r + S0r;
             gim = -(S1i - S0i);
         }
@@ -624,16 +627,12 @@ __global__ __launch_bounds__(256) void k_factor_bwd_direct_global(FactorBwdArgs 
     const double2* __restrict__ xin = a.xin + boff;
     const double* __restrict__ cf = a.coef + blockIdx.y * a.coef_bstride;
     double* __restrict__ ge = a.ge + blockIdx.y * a.ge_bstride + (wg % kGradReplicas) * a.ge_rstride;
-    double2 pg[NQ], px[NQ];
+    double2 pg[NQ];
 #pragma unroll
-    for (int j = 0; j < NQ; ++j) {
-        pg[j] = gin[x ^ (1u << j)];
-        px[j] = xin[x ^ (1u << j)];
-    }
+    for (int j = 0; j < NQ; ++j) pg[j] = gin[x ^ (1u << j)];
     const double2 gy = gin[x], xi = xin[x];
     const double d = diag_value(a.udiag, cf, a.g, x);
     double gsr = 0.0, gsi = 0.0, gdr = 0.0, gdi = 0.0;  // plain / signed partner sums of the cotangent
-    double xsr = 0.0, xsi = 0.0, xdr = 0.0, xdi = 0.0;  // ... of the factor input
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
         const double sgn = (x >> j & 1u) ? 1.0 : -1.0;
@@ -641,10 +640,6 @@ __global__ __launch_bounds__(256) void k_factor_bwd_direct_global(FactorBwdArgs 
         gsi += pg[j].y;
         gdr = fma(sgn, pg[j].x, gdr);
         gdi = fma(sgn, pg[j].y, gdi);
-        xsr += px[j].x;
-        xsi += px[j].y;
-        xdr = fma(sgn, px[j].x, xdr);
-        xdi = fma(sgn, px[j].y, xdi);
     }
     const double cr = cf[0], ci = cf[1];
     // adjoint matvec: conj(gamma + beta d) gy + conj(beta) (cr*gs + i*ci*gd)
@@ -661,8 +656,13 @@ __global__ __launch_bounds__(256) void k_factor_bwd_direct_global(FactorBwdArgs 
     const double pr = a.br * gy.x + a.bi * gy.y, pi = a.bi * gy.x - a.br * gy.y;
     const double r = pr * xi.x - pi * xi.y;  // Re(beta conj(gy) xi)
     if (a.wtot) unsafeAtomicAdd(a.wtot + x, r);
+    // dL/dRe c = Re sum_x a_(x) xs(x), dL/dIm c = -Im sum_x a_(x) xd(x) with xs / xd the plain / signed partner sums of the TAPE
+    // vector — re-indexed over the partner: sum_x a_ xs = sum_y xin(y) beta conj(gs(y)), sum_x a_ xd = -sum_y xin(y) beta conj(gd(y))
+    // (flipping bit j toggles its sign): the cotangent's partner sums and the own tape element, no partner loads of the tape.
+    const double qsr = a.br * gsr + a.bi * gsi, qsi = a.bi * gsr - a.br * gsi;  // beta conj(gs)
+    const double qdr = a.br * gdr + a.bi * gdi, qdi = a.bi * gdr - a.br * gdi;  // beta conj(gd)
     // the two drive gradients and the first detuning gradient share ONE workgroup reduction (one pair of barriers)
-    double v0 = wave_sum(pr * xsr - pi * xsi), v1 = wave_sum(-(pr * xdi + pi * xdr));
+    double v0 = wave_sum(qsr * xi.x - qsi * xi.y), v1 = wave_sum(qdr * xi.y + qdi * xi.x);
     double v2 = wave_sum(a.g.gd > 0 ? r * double(a.g.dcnt[0] - popc_i(x & a.g.dmask[0])) : 0.0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) {

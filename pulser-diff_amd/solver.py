@@ -195,6 +195,9 @@ class _RydbergEvolve(torch.autograd.Function):
         _check_shapes(spec, amp_c, det_c, u_c, obs_c, batch)
         n_t = len(ts_host)
         call = _Call(spec, amp_c, det_c, u_c, ts_host, batch, obs_c)
+        # the kernel variant this call resolved to (spec field, else the CALLING thread's default): the backward pass runs on the
+        # autograd engine's device thread, where that thread-local default is not visible
+        ctx.kernel_variant = int(call.problem.kernel_variant)
         needs_grad = any(ctx.needs_input_grad[:5])
         need_tape = int(bool(needs_grad and not spec.store_states))
         with torch.cuda.device(dev):
@@ -258,6 +261,7 @@ class _RydbergEvolve(torch.autograd.Function):
         batch, dim = psi_c.shape
         obs = obs_c if ctx.has_obs else None
         call = _Call(spec, amp_c, det_c, u_c, ctx.tsave_host, batch, obs, real_amp_grad=not ctx.in_dtypes[0].is_complex)
+        call.problem.kernel_variant = ctx.kernel_variant  # same kernel family as the forward pass (see forward)
         need = ctx.needs_input_grad
         if g_states is not None and g_states.numel() == 0:
             g_states = None
