@@ -117,7 +117,7 @@ typedef struct RydProblem {
      *   8 automatic, but the LDS-tile persistent kernels also up to 6 qubits (instead of the one-wave lane kernels)
      *  10 chained passes with trajectory-per-XCD placement forced (L2-resident trajectories)
      * "automatic" takes the one-launch sweeps up to 12 qubits, the direct kernels while few tiles are in flight
-     * (B * 2^N <= 2^18) and the chained passes beyond.  Results do not depend on the variant beyond rounding. */
+     * (B * 2^N <= 2^18, with gradients 2^19) and the chained passes beyond.  Results do not depend on the variant beyond rounding. */
     int32_t kernel_variant;
 
     /* STATE-SHARDED forward runs (BASELINE config 5; the reference has no counterpart: it keeps the whole

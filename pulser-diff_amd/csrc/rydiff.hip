@@ -1171,8 +1171,11 @@ void fill_info(const Runtime& rt, double lo, double hi, size_t ws, RydPlanInfo* 
 bool few_tiles(const Runtime& rt, bool with_gradients) {
     const Plan& pl = rt.pl;
     if (rt.variant != 0 || rt.force_three || rt.force_xcd || pl.shard_bits) return false;
-    (void)with_gradients;  // with the unrolled global-drive direct kernels the crossover is 2^18 amplitudes either way
-    return (size_t(pl.B) << pl.N) <= (size_t(1) << 18);
+    // forward only: crossover at 2^18 amplitudes in flight (N = 19: 12.5 us direct vs 10.8 us chained per pass).  With gradients the
+    // direct ADJOINT pass (own tape element only, partner reads of the cotangent served by L2) stays ahead of the chained one up to
+    // 2^19 (11.6-12.8 vs 14.0-14.7 us) and the pair of passes wins by 1-7 % there (profiles/r02_crossover_direct_vs_chained.txt);
+    // at 2^20 (C3, C4's 16 x 2^16) the chained tiles win both passes.
+    return (size_t(pl.B) << pl.N) <= (size_t(1) << (with_gradients ? 19 : 18));
 }
 
 // The full per-factor tape (the adjoint sweep recomputes nothing) goes with the launch-per-factor ADJOINT kernels, chained or

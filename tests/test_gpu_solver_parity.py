@@ -431,7 +431,7 @@ def test_real_amplitude_tables_give_the_real_part_of_the_gradient(cuda_device, n
 
 
 def test_automatic_kernel_choice_by_tiles_in_flight(cuda_device):
-    """One 14-qubit trajectory (4 tiles) runs on the direct kernels, 16 such trajectories (2^18 amplitudes in flight) on the
+    """One 14-qubit trajectory (4 tiles) runs on the direct kernels, 64 such trajectories (2^20 amplitudes in flight) on the
     chained tiles; both keep the full per-factor tape when asked to (RydPlanInfo.tape_mode), and give the same gradients
     per trajectory."""
     from pulser_diff_amd.solver import ProblemSpec, SolverType, evolve
@@ -443,16 +443,16 @@ def test_automatic_kernel_choice_by_tiles_in_flight(cuda_device):
     psi0 = R.all_ground_state(n).T.contiguous().to(cuda_device)
     obs = R.total_magnetization_diag(n)[None].to(cuda_device)
     grads = {}
-    for batch in (1, 16):
+    for batch, family in ((1, "direct"), (64, "chained-tiles")):
         spec = ProblemSpec(n, spec0.dt, spec0.n_samples, spec0.amp_masks, spec0.det_masks, solver=SolverType.KRYLOV_SE,
                            store_states=False, tape="full")
         a = amp.clone().requires_grad_(True)
         d = det.clone().requires_grad_(True)
         _, expect = evolve(a, d, u, tsave, psi0.repeat(batch, 1), spec, obs)
         expect[0, -1, :].sum().backward()
-        assert spec.options["_last_stats"]["tape"] == "full"
+        assert spec.options["_last_stats"]["tape"] == "full" and spec.options["_last_stats"]["kernel_family"] == family
         grads[batch] = (expect[0, :, 0].detach().cpu().numpy(), a.grad.cpu().numpy() / batch, d.grad.cpu().numpy() / batch)
-    for x, y in zip(grads[1], grads[16]):
+    for x, y in zip(grads[1], grads[64]):
         assert rel_err(y, x) < 1e-10
 
 
