@@ -361,7 +361,7 @@ def run_trajectories(args, workload: str, rank: int, world: int, device, barrier
                                + f"KRYLOV_SE map, {total} parameter set(s) in the job",
                    "n_qubits": n_qubits, "time_steps": T, "trajectories_total": total, "trajectories_this_rank": mine,
                    "trajectories_per_solver_call": chunk, "ranks": world, "gathered_parameter_sets": gathered_sets,
-                   "parallelism": f"trajectory-sharded x{world}" + (" (256 sets dealt in contiguous blocks)" if workload == "c4" else " (one replica per rank)"),
+                   "parallelism": f"trajectory-sharded x{world}" + (f" ({total} sets dealt in contiguous blocks)" if workload == "c4" else " (one replica per rank)"),
                    "matvecs_per_step_fwd": stats.get("degree", 0), "kernel_family": stats.get("kernel_family"),
                    "tape": stats.get("tape")},
         "loss": float(loss),
