@@ -374,7 +374,7 @@ class TorchEmulator:
             if n > MAX_ME_QUBITS:
                 raise ValueError(f"The master-equation solver keeps 4^N amplitudes; limited to {MAX_ME_QUBITS} qubits.")
             amp, det, u_pairs, amp_masks, det_masks = doubled_tables(amp, det, u_pairs, amp_masks, det_masks, n)
-            block = dissipator_block(local_collapse_operators(ham.config))
+            block = dissipator_block(local_collapse_operators(ham.config, ham.basis_name))
             spec = ProblemSpec(2 * n, ham.dt, ham.n_samples, amp_masks, det_masks, solver=SolverType.DP5_SE,
                                tol=tolerance_from_options(options) or ME_DEFAULT_TOL, store_states=True,
                                pair_terms=tuple((j, n + j, block) for j in range(n)))

@@ -38,12 +38,16 @@ _Y = np.array([[0, -1j], [1j, 0]], dtype=complex)
 _SIGMA_GR = np.array([[0, 0], [1, 0]], dtype=complex)  # |g><r| (op_matrix["sigma_gr"], hamiltonian.py:108-115)
 
 
-def local_collapse_operators(cfg: NoiseModel) -> list:
-    """The single-qubit collapse operators of ``hamiltonian.py:98-143`` (each is applied to every qubit)."""
+def local_collapse_operators(cfg: NoiseModel, basis_name: str = "ground-rydberg") -> list:
+    """The single-qubit collapse operators of ``hamiltonian.py:98-143`` (each is applied to every qubit).  In the digital basis the
+    dephasing rate is the hyperfine one (:106-111) and relaxation — built on sigma_gr — is refused (:113-120)."""
     ops = []
     if "dephasing" in cfg.noise_types:
-        ops.append(np.sqrt(cfg.dephasing_rate / 2) * _Z)
+        rate = cfg.hyperfine_dephasing_rate if basis_name == "digital" else cfg.dephasing_rate
+        ops.append(np.sqrt(rate / 2) * _Z)
     if "relaxation" in cfg.noise_types:
+        if basis_name != "ground-rydberg":
+            raise ValueError("'relaxation' noise requires addressing of the 'ground-rydberg' basis.")
         ops.append(np.sqrt(cfg.relaxation_rate) * _SIGMA_GR)
     if "depolarizing" in cfg.noise_types:
         c = np.sqrt(cfg.depolarizing_rate / 4)
@@ -98,7 +102,7 @@ def mesolve(ham, psi0: Tensor, tsave: Tensor, noise: NoiseModel, options: Option
     options = dict(options or {})
     dev = ham.amp_tables.device
     amp2, det2, u2, am2, dm2 = doubled_tables(ham.amp_tables, ham.det_tables, ham.u_pairs, ham.amp_masks, ham.det_masks, n)
-    block = dissipator_block(local_collapse_operators(noise))
+    block = dissipator_block(local_collapse_operators(noise, getattr(ham, "basis_name", "ground-rydberg")))
     pair_terms = tuple((j, n + j, block) for j in range(n)) if np.any(block != 0) else ()
     # default accuracy target one decade below the ket solver's: the calibration of the Magnus step is a little optimistic
     # for non-normal (dissipative) generators

@@ -184,3 +184,31 @@ def test_pair_terms_on_direct_and_persistent_kernels_agree(cuda_device):
             _native.set_kernel_variant(0)
     for name, ref, got in zip(("rho", "amp", "det", "u", "tsave"), out[1], out[0]):
         assert rel_err(got, ref) < 1e-10, name
+
+
+def test_digital_basis_dephasing_uses_the_hyperfine_rate_and_refuses_relaxation(cuda_device):
+    """hamiltonian.py:106-120: in the digital basis the dephasing collapse operator is sqrt(hyperfine_dephasing_rate / 2) Z (not the
+    Rydberg dephasing rate) and relaxation, which is built on sigma_gr, raises ValueError."""
+    import pulser_diff_amd as P
+    from pulser_diff_amd import pulses as pl
+
+    seq = pl.Sequence(pl.Register.from_coordinates([[0.0, 0.0], [7.0, 0.0]]), pl.MockDevice)
+    seq.declare_channel("ram", "raman_global")
+    seq.add(pl.Pulse(pl.BlackmanWaveform(120, 2.4), pl.RampWaveform(120, -3.0, 2.0), 0.3), "ram")
+    sim = P.TorchEmulator.from_sequence(seq, sampling_rate=0.5, compute_device="cuda")
+    assert sim.basis_name == "digital"
+    sim.set_config(P.SimConfig(noise="dephasing", dephasing_rate=5.0, hyperfine_dephasing_rate=0.8))
+    res = sim.run()  # collapse operators force the master equation (backend.py:482-488)
+    rho = res.states[..., 0].cpu().numpy()
+    ham = sim._hamiltonian
+    terms = R.HamTerms(2, torch.zeros(1, dtype=torch.float64), ham.amp_tables[0, 0].cpu(), ham.det_tables[0, 0].cpu(), ham.dt, ham.n_samples,
+                       [0, 1], [0, 1])  # digital basis: same drive structure, no interaction term (hamiltonian.py:460)
+    psi0 = sim.initial_state[:, 0]
+    ts = sim.evaluation_times.detach().cpu().numpy()
+    ref = R.lindblad_continuous_solution(terms, R.collapse_operators(2, {"dephasing": 0.8}), torch.outer(psi0, psi0.conj()).numpy(), ts)
+    assert np.abs(rho - ref).max() < 1e-8
+    wrong = R.lindblad_continuous_solution(terms, R.collapse_operators(2, {"dephasing": 5.0}), torch.outer(psi0, psi0.conj()).numpy(), ts)
+    assert np.abs(rho - wrong).max() > 1e-3
+    sim.set_config(P.SimConfig(noise="relaxation", relaxation_rate=0.3))
+    with pytest.raises(ValueError, match="requires addressing of the 'ground-rydberg' basis"):
+        sim.run()
