@@ -321,7 +321,7 @@ class TorchEmulator:
         if "SPAM" in noise:
             meas_errors = {k: self.config.spam_dict[k] for k in ("epsilon", "epsilon_prime")}
             ground = torch.zeros_like(self.initial_state)
-            ground[-1] = 1.0
+            ground[-1 if self._hamiltonian.basis_name == "ground-rydberg" else 0] = 1.0  # |g..g>: last vector of (r, g), first of (g, h)
             if self.config.eta > 0 and not torch.equal(self.initial_state, ground):
                 raise NotImplementedError("Can't combine state preparation errors with an initial "
                                           "state different from the ground.")
@@ -403,8 +403,9 @@ class TorchEmulator:
                 for b in range(r1 - r0):
                     n_shots = self.config.samples_per_run * reps[r0 + b]
                     idx = torch.multinomial(probs[:, b, :], n_shots, replacement=True)  # (n_t, shots)
-                    # measured bitstring: '1' = Rydberg = index bit 0 (result.py:70-120), i.e. the complement of the index
-                    shots = (dim - 1) - idx
+                    # measured bitstring (result.py:70-120): ground-rydberg '1' = r = index bit 0, i.e. the complement of the index;
+                    # digital / XY '1' = h / d = index bit 1: the index itself
+                    shots = (dim - 1) - idx if ham.basis_name == "ground-rydberg" else idx
                     if eps > 0 or eps_p > 0:
                         bits = (shots.unsqueeze(-1) >> torch.arange(n, device=dev)) & 1
                         flip = torch.rand(bits.shape, device=dev) < torch.where(bits == 1, eps_p, eps)

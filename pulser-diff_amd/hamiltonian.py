@@ -207,8 +207,10 @@ class Hamiltonian:
             if self.samples["Global"]:
                 raise RuntimeError("noise realisations need per-qubit samples")
             for basis, per_q in self.samples["Local"].items():
-                if basis != "ground-rydberg":
-                    raise NotImplementedError("Only the ground-rydberg basis is supported.")
+                if not per_q:
+                    continue
+                if basis != self.basis_name or self.basis_name == "all":  # (the two-level bases share the drive structure)
+                    raise NotImplementedError(f"Stochastic noise on {basis!r} samples in the {self.basis_name!r} basis is not supported.")
                 for qid, sq in per_q.items():
                     j = self._qid_index[qid]
                     amp[r, j] = self._adapt_to_sampling_rate(0.5 * sq["amp"] * torch.exp(-1j * sq["phase"].to(CD)))

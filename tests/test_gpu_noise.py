@@ -107,3 +107,29 @@ def test_preparation_and_detection_errors(cuda_device):
         sim = P.TorchEmulator.from_sequence(seq, config=cfg)
         sim.set_initial_state(torch.ones(2**n, dtype=torch.complex128) / np.sqrt(2**n))
         sim.run(solver=SolverType.KRYLOV_SE)
+
+
+def test_stochastic_noise_in_the_digital_basis(cuda_device):
+    """The digital basis shares the drive structure (hamiltonian.py:410-416), so its noisy runs are the same batch of trajectories; the
+    measured '1' is |h> = index bit 1 (result.py:70-120: no inversion, unlike ground-rydberg).  Vanishing Doppler noise must give
+    the coherent distribution, thermal detuning must change it."""
+    n = 3
+    seq = pl.Sequence(pl.Register.rectangle(1, n, spacing=8, prefix="q"), pl.MockDevice)
+    seq.declare_channel("ram", "raman_global")
+    seq.add(pl.Pulse(pl.BlackmanWaveform(300, 2.4), pl.RampWaveform(300, -3.0, 2.0), 0.0), "ram")
+    times = [0.1, 0.2, 0.3]
+    clean = P.TorchEmulator.from_sequence(seq, evaluation_times=times).run(solver=SolverType.KRYLOV_SE)
+    p_clean = (clean.states[-1, :, 0].abs() ** 2).cpu().numpy()  # bitstring order = index order: '1' = h
+    assert p_clean[0] < 0.9  # the pulse moves population out of |ggg>
+    torch.manual_seed(5)
+    sim = P.TorchEmulator.from_sequence(seq, config=P.SimConfig(noise="doppler", temperature=0.0, runs=10, samples_per_run=1000),
+                                        evaluation_times=times)
+    assert sim.basis_name == "digital"
+    res = sim.run(solver=SolverType.KRYLOV_SE)
+    assert isinstance(res, NoisyResults) and res.results[0] == Counter({"0" * n: 1.0})
+    p_noisy = np.array([res.results[-1].get(np.binary_repr(i, n), 0.0) for i in range(2**n)])
+    assert np.abs(p_noisy - p_clean).max() < 5 * 0.5 / np.sqrt(10 * 1000)
+    hot = P.TorchEmulator.from_sequence(seq, config=P.SimConfig(noise="doppler", temperature=5000.0, runs=10, samples_per_run=1000),
+                                        evaluation_times=times).run(solver=SolverType.KRYLOV_SE)
+    p_hot = np.array([hot.results[-1].get(np.binary_repr(i, n), 0.0) for i in range(2**n)])
+    assert np.abs(p_hot - p_clean).max() > 0.03
