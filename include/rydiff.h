@@ -160,6 +160,13 @@ typedef struct RydProblem {
      * problems run on the generic one-amplitude-per-thread kernels (forward, adjoint, every gradient), any register size. */
     uint64_t amp_conditioned_terms;
     uint64_t det_ones_terms;
+
+    /* RYDIFF_SOLVER_DP5_SE only, optional (NULL: none).  HOST uint8 [n_samples - 1]: entry i multiplies the number of Magnus
+     * sub-steps taken on the linear piece between samples i and i + 1 (0 and 1: unchanged).  The sub-step is sized from the
+     * generator's width; the error constant also carries dH/dt, so a piece across which a table JUMPS (the edge of a constant
+     * pulse inside one sample interval) wants a finer step than the smooth pieces — a caller that builds the tables on the host
+     * knows where that is (pulser-diff_amd/hamiltonian.py: piece_refinement) and the library does not have to read them back. */
+    const uint8_t* dp5_piece_refine;
 } RydProblem;
 
 /* Result of rydiff_plan(): everything that depends on the VALUES in the coefficient tables. */

@@ -62,6 +62,7 @@ class RydProblem(ctypes.Structure):
         ("final_state_only", ctypes.c_int32),
         ("amp_conditioned_terms", ctypes.c_uint64),
         ("det_ones_terms", ctypes.c_uint64),
+        ("dp5_piece_refine", ctypes.c_void_p),
     ]
 
 

@@ -330,7 +330,11 @@ inline bool build_plan(const RydProblem* p, Plan& pl, std::string& err, double w
             for (int q = 0; q < np; ++q) {
                 const double p0 = pts[q], p1 = pts[q + 1], hf = p1 - p0;
                 const int lo_owner = (q == 0) ? k : -1, hi_owner = (q == np - 1) ? k + 1 : -1;
-                const int S = std::max(1, int(std::ceil(hf / h_max - 1e-9)));
+                int S = std::max(1, int(std::ceil(hf / h_max - 1e-9)));
+                if (p->dp5_piece_refine && n >= 2) {  // caller's hint: pieces across which the coefficient tables jump
+                    const long si = std::min(std::max(long(std::floor(0.5 * (p0 + p1) / pl.dt)), 0L), long(n) - 2);
+                    S *= std::max(1, int(p->dp5_piece_refine[si]));
+                }
                 for (int sub = 0; sub < S; ++sub)
                     for (double theta : {1.0 / 6.0, 5.0 / 6.0}) {
                         Stage s{};

@@ -335,7 +335,26 @@ class Hamiltonian:
         # real-valued drives: the solver is handed the REAL part of the tables, so that autograd only asks for dL/dRe(amp)
         # and the native adjoint skips the dL/dIm(amp) contractions (RydProblem.real_amp_grad)
         self.amp_is_real = bool(amp_terms) and phase_free[0]
+        self.piece_refine = self._piece_refinement(amp_terms, det_terms)
         self._hamiltonian = self.build_ham_tensor()
+
+    # The continuous-time solver sizes its Magnus sub-step from the generator's width; the error constant of a linear piece also
+    # carries ||dH/dt||, calibrated on smooth pulses (a Blackman pulse on a few atoms: ~1e2 rad/us^2).  A piece across which a
+    # table JUMPS — the edge of a constant pulse inside one sample interval — is far above that: such pieces get
+    # round((||dH/dt|| / ref)^(1/4)) times the sub-steps (error ~ h^4).  Built here because the tables are still on the host.
+    _DHDT_REF = 100.0  # rad/us^2
+
+    def _piece_refinement(self, amp_terms: list, det_terms: list):
+        ns = self.n_samples
+        if ns < 2 or not (amp_terms or det_terms):
+            return None
+        jump = torch.zeros(ns - 1, dtype=RD)
+        for c, mask in amp_terms:
+            jump = jump + (c.detach()[1:] - c.detach()[:-1]).abs().to(RD) * bin(mask).count("1")
+        for d, mask in det_terms:
+            jump = jump + 2.0 * (d.detach()[1:] - d.detach()[:-1]).abs().to(RD) * bin(mask).count("1")
+        scale = torch.floor((jump / self.dt / self._DHDT_REF) ** 0.25 + 0.5).clamp(1, 8).to(torch.uint8)
+        return scale.numpy() if bool((scale > 1).any()) else None
 
     def _rebuild_u_pairs(self) -> None:
         """U_ij = C6 / r_ij^6 from the stored distance tensors (hamiltonian.py:341-344).  The digital basis has no
@@ -394,7 +413,8 @@ class Hamiltonian:
                      store_states: bool = True) -> ProblemSpec:
         return ProblemSpec(self.n_solver_qubits, self.dt, self.n_samples, self.amp_masks, self.det_masks, solver=solver, tol=tol,
                            store_states=store_states, pair_terms=tuple(getattr(self, "pair_terms", ())),
-                           amp_conditioned=self._amp_cond, det_ones=self._det_ones)
+                           amp_conditioned=self._amp_cond, det_ones=self._det_ones,
+                           piece_refine=self.piece_refine if solver == SolverType.DP5_SE else None)
 
     # ---- three-level registers on the two-level solver ------------------------------------------------------------------
     @property

@@ -58,6 +58,8 @@ class ProblemSpec:
     # three-level registers as two qubits per atom (include/rydiff.h, amp_conditioned_terms / det_ones_terms): per-term flags
     amp_conditioned: tuple = ()   # () or one bool per amplitude term: the flip acts only where the sibling qubit (j ^ 1) is 1
     det_ones: tuple = ()          # () or one bool per detuning term: the term counts the ones of its mask with minus its coefficient
+    # DP5_SE: optional uint8 array [n_samples - 1], multiplier of the Magnus sub-steps per sample interval (RydProblem.dp5_piece_refine)
+    piece_refine: Optional[Any] = None
 
     def solver_code(self) -> int:
         if self.solver not in _SOLVER_CODE:
@@ -134,6 +136,12 @@ class _Call:
         p.kernel_variant = _native.default_kernel_variant() if spec.kernel_variant is None else int(spec.kernel_variant)
         p.amp_conditioned_terms = sum(1 << k for k, f in enumerate(spec.amp_conditioned) if f)
         p.det_ones_terms = sum(1 << k for k, f in enumerate(spec.det_ones) if f)
+        self.piece_refine = None
+        if spec.piece_refine is not None and spec.n_samples >= 2:
+            self.piece_refine = np.ascontiguousarray(np.clip(np.asarray(spec.piece_refine), 0, 255), dtype=np.uint8)
+            if self.piece_refine.shape != (spec.n_samples - 1,):
+                raise ValueError(f"piece_refine must have n_samples - 1 = {spec.n_samples - 1} entries, got {self.piece_refine.shape}")
+            p.dp5_piece_refine = self.piece_refine.ctypes.data
         self.problem = p
 
 

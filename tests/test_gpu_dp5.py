@@ -143,3 +143,37 @@ def test_continuous_solver_on_chained_tile_kernels_matches_direct_kernels(cuda_d
             _native.set_kernel_variant(0)
     for name, ref, got in zip(("expect", "amp", "det", "u", "tsave"), out[1], out[2]):
         assert rel_err(got.numpy(), ref.numpy()) < 1e-10, name
+
+
+def test_piece_refinement_hint_tightens_pieces_with_jumps(cuda_device):
+    """RydProblem.dp5_piece_refine: a table that JUMPS inside one sample interval (the edge of a constant pulse) carries a much
+    larger error constant than the smooth pieces the Magnus sub-step is calibrated on.  With the per-piece multiplier the emulator
+    derives from the host-side tables (hamiltonian.py:_piece_refinement) the error against the continuous solution drops by
+    about the fourth power of the multiplier on exactly those pieces, at a handful of extra stages."""
+    from pulser_diff_amd.solver import ProblemSpec, SolverType, evolve
+
+    n, ns, dt = 5, 40, 0.002
+    terms = random_terms(n, ns, dt, seed=17, local=False, phase=False, spacing=6.5)
+    edge = torch.zeros(ns, dtype=torch.float64)
+    edge[10:25] = 3.0  # a 3 rad/us constant pulse switched on and off within one sample interval each
+    terms.amp_coeff = (0.5 * edge).to(torch.complex128)
+    amp, det, u, spec0 = to_native(terms, cuda_device, SolverType.DP5_SE, store_states=True)
+    tsave = torch.linspace(0, dt * (ns - 2), 9, dtype=torch.float64)
+    psi0 = R.all_ground_state(n)
+    cont = R.continuous_solution(terms, psi0.numpy(), tsave.numpy())
+    refine = np.ones(ns - 1, dtype=np.uint8)
+    refine[[9, 24]] = 3
+    errs, stages = {}, {}
+    for name, hint in (("plain", None), ("refined", refine)):
+        spec = ProblemSpec(spec0.n_qubits, spec0.dt, spec0.n_samples, spec0.amp_masks, spec0.det_masks, solver=SolverType.DP5_SE,
+                           store_states=True, piece_refine=hint)
+        states, _ = evolve(amp, det, u, tsave, psi0.T.contiguous().to(cuda_device), spec, None)
+        errs[name] = np.abs(states.cpu().permute(0, 2, 1).numpy() - cont).max()
+        stages[name] = spec.options["_last_stats"]["n_stages"]
+    # two pieces (cut once more where a save point falls inside), three sub-steps instead of one, two exponentials each
+    assert stages["plain"] < stages["refined"] <= stages["plain"] + 16
+    assert errs["refined"] < 0.1 * errs["plain"] and errs["refined"] < 2e-9, errs
+    with pytest.raises(ValueError, match="n_samples - 1"):
+        evolve(amp, det, u, tsave, psi0.T.contiguous().to(cuda_device),
+               ProblemSpec(spec0.n_qubits, spec0.dt, spec0.n_samples, spec0.amp_masks, spec0.det_masks, solver=SolverType.DP5_SE,
+                           piece_refine=np.ones(3, dtype=np.uint8)), None)

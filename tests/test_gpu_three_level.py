@@ -110,9 +110,11 @@ def test_three_level_sequence_through_the_emulator(cuda_device, solver_name, loc
         sol = solve_ivp(lambda t, y: (-1j * (H_ref(t) @ torch.from_numpy(y))).numpy(), (0.0, float(ts[-1])), psi0[:, 0].numpy(),
                         method="DOP853", t_eval=ts.numpy(), rtol=1e-12, atol=1e-14, max_step=ham.dt)
         cont = torch.from_numpy(sol.y.T)
-        # 6.5 um between the first two atoms: U = 72 rad/us, |rrr> at 150 rad/us — beyond the range the default sub-step of the
-        # commutator-free Magnus scheme is calibrated on (csrc/plan.hpp): 7e-8 there, and it converges with `tol` (error ~ h^4)
-        assert (states[:, :, 0] - cont).abs().max() < 2e-7
+        # 6.5 um between the first two atoms (U = 72 rad/us, |rrr> at 150 rad/us), a 41 rad/us Blackman peak and 2-3 rad/us pulse
+        # edges inside single 2-ns sample intervals: without the per-piece refinement of the sub-steps (hamiltonian.py:
+        # _piece_refinement -> RydProblem.dp5_piece_refine) the default target gave 7e-8 here
+        assert ham.piece_refine is not None and int(ham.piece_refine.max()) >= 2
+        assert (states[:, :, 0] - cont).abs().max() < 1e-8
         tight = sim.run(solver=SolverType.DP5_SE, tol=1e-12).states.detach().cpu()
         assert (tight[:, :, 0] - cont).abs().max() < 2e-9
     # populations move out of |ggg> into both other levels
