@@ -107,7 +107,8 @@ def mesolve(ham, psi0: Tensor, tsave: Tensor, noise: NoiseModel, options: Option
     # default accuracy target one decade below the ket solver's: the calibration of the Magnus step is a little optimistic
     # for non-normal (dissipative) generators
     spec = ProblemSpec(2 * n, ham.dt, ham.n_samples, am2, dm2, solver=SolverType.DP5_SE,
-                       tol=tolerance_from_options(options) or ME_DEFAULT_TOL, store_states=True, pair_terms=pair_terms)
+                       tol=tolerance_from_options(options) or ME_DEFAULT_TOL, store_states=True, pair_terms=pair_terms,
+                       piece_refine=getattr(ham, "piece_refine", None))  # same time structure on the doubled register
     psi = psi0.to(dev, CD)
     if psi.ndim == 1:
         psi = psi.unsqueeze(1)
