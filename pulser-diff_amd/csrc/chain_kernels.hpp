@@ -152,7 +152,9 @@ __device__ __forceinline__ void park1(double v0, double* red, int slot0) {
 }
 
 // partner sums over the tile bits in `mask`:  ts[r] = sum of partners, ds[r] = sum(+partner if own bit set else -partner)
-template <int LT, int LGT, bool CPLX, bool FULL = false>  // FULL: every tile bit is in the mask (no per-bit tests)
+// COND (one-launch kernels only: the tile IS the register, tile bit = amplitude-index bit): conditioned flips of a three-level
+// register (RydProblem.amp_conditioned_terms) — the flip of bit b counts only for amplitudes whose sibling bit b ^ 1 is 1.
+template <int LT, int LGT, bool CPLX, bool FULL = false, bool COND = false>  // FULL: every tile bit is in the mask (no per-bit tests)
 __device__ __forceinline__ void partner_sums(const double2* __restrict__ tile, const double2 (&reg)[1 << (LT - LGT)],
                                              uint32_t mask, unsigned tid, double2 (&ts)[1 << (LT - LGT)],
                                              double2 (&ds)[1 << (LT - LGT)]) {
@@ -169,6 +171,7 @@ __device__ __forceinline__ void partner_sums(const double2* __restrict__ tile, c
                 const double sgn = (tid >> b & 1u) ? 1.0 : -1.0;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
+                    if (COND && !((unsigned(r) * NT + tid) >> (b ^ 1) & 1u)) continue;
                     const double2 q = tile[(unsigned(r) * NT + tid) ^ (1u << b)];
                     ts[r].x += q.x;
                     ts[r].y += q.y;
@@ -180,6 +183,7 @@ __device__ __forceinline__ void partner_sums(const double2* __restrict__ tile, c
             } else {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
+                    if (COND && !((unsigned(r) * NT + tid) >> (b ^ 1) & 1u)) continue;
                     const double2 q = reg[r ^ (1 << (b - LGT))];
                     ts[r].x += q.x;
                     ts[r].y += q.y;
@@ -229,7 +233,7 @@ __device__ __forceinline__ double2 lane_xor(const double2& v) {
     return make_double2(__hiloint2double(a1, a0), __hiloint2double(b1, b0));
 }
 
-template <int LT, bool CPLX, bool FULL = false>
+template <int LT, bool CPLX, bool FULL = false, bool COND = false>
 __device__ __forceinline__ void partner_sums_lanes(const double2& own, uint32_t mask, unsigned tid, double2& ts, double2& ds) {
     static_assert(LT <= 6, "one amplitude per lane");
     ts = make_double2(0.0, 0.0);
@@ -238,7 +242,8 @@ __device__ __forceinline__ void partner_sums_lanes(const double2& own, uint32_t 
         constexpr int b = decltype(bc)::value;
         if constexpr (b < LT) {
             if (FULL || (mask >> b & 1u)) {  // wave-uniform
-                const double2 q = lane_xor<b>(own);
+                double2 q = lane_xor<b>(own);  // (every lane takes part in the exchange; the condition only masks the sum)
+                if (COND && !(tid >> (b ^ 1) & 1u)) q = make_double2(0.0, 0.0);
                 ts.x += q.x;
                 ts.y += q.y;
                 if (CPLX) {

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64) void k_lanes_fwd(PersistArgs a) {
             for (int g = 0; g < GL; ++g) {
                 if (FAST || g < a.ga) {
                     double2 ts, ds;
-                    partner_sums_lanes<LT, CPLX, FAST>(v, a.amask[g], lane, ts, ds);
+                    do { if (!FAST && (a.cond >> g & 1u)) partner_sums_lanes<LT, CPLX, false, true>(v, a.amask[g], lane, ts, ds); else partner_sums_lanes<LT, CPLX, FAST>(v, a.amask[g], lane, ts, ds); } while (0);
                     const double cr = bcast_lane(cur.cr[g], fs);
                     const double k1r = br * cr, k1i = bi * cr;
                     q.x += k1r * ts.x - k1i * ts.y;
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64) void k_lanes_bwd(PersistBwdArgs a) {
             for (int g = 0; g < GL; ++g) {
                 if (FAST || g < a.ga) {
                     double2 ts, ds;
-                    partner_sums_lanes<LT, CPLX, FAST>(v, a.amask[g], lane, ts, ds);
+                    do { if (!FAST && (a.cond >> g & 1u)) partner_sums_lanes<LT, CPLX, false, true>(v, a.amask[g], lane, ts, ds); else partner_sums_lanes<LT, CPLX, FAST>(v, a.amask[g], lane, ts, ds); } while (0);
                     const double cr = bcast_lane(cur.cr[g], fs);
                     const double k1r = br * cr, k1i = bi * cr;
                     q.x += k1r * ts.x - k1i * ts.y;
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(64) void k_lanes_bwd(PersistBwdArgs a) {
             for (int g = 0; g < GL; ++g) {
                 if (FAST || g < a.ga) {
                     double2 ts, ds;
-                    partner_sums_lanes<LT, true, FAST>(mu, a.amask[g], lane, ts, ds);
+                    do { if (!FAST && (a.cond >> g & 1u)) partner_sums_lanes<LT, true, false, true>(mu, a.amask[g], lane, ts, ds); else partner_sums_lanes<LT, true, FAST>(mu, a.amask[g], lane, ts, ds); } while (0);
                     const double cr = bcast_lane(cur.cr[g], fs), ci = bcast_lane(cur.ci[g], fs);
                     // (F_g mu) = cr * ts + i * ci * ds
                     hm.x += cr * ts.x - ci * ds.y;
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(64) void k_lanes_bwd_tape(PersistBwdArgs a) {
         for (int g = 0; g < GL; ++g) {
             if (FAST || g < a.ga) {
                 double2 ts, ds;
-                partner_sums_lanes<LT, true, FAST>(mu, a.amask[g], lane, ts, ds);
+                do { if (!FAST && (a.cond >> g & 1u)) partner_sums_lanes<LT, true, false, true>(mu, a.amask[g], lane, ts, ds); else partner_sums_lanes<LT, true, FAST>(mu, a.amask[g], lane, ts, ds); } while (0);
                 const double cr = bcast_lane(cur.cr[g], fs), ci = bcast_lane(cur.ci[g], fs);
                 hm.x += cr * ts.x - ci * ds.y;
                 hm.y += cr * ts.y + ci * ds.x;

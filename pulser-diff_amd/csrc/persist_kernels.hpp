@@ -62,6 +62,7 @@ struct PersistArgs {
     uint32_t amask[kMaxGroups];
     uint32_t dmask[kMaxGroups];
     int dcnt[kMaxGroups];
+    uint32_t cond;            // amplitude groups with conditioned flips (three-level registers, RydProblem.amp_conditioned_terms)
     PairArgs pair;
 };
 
@@ -161,10 +162,10 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist(P
             auto amp_group = [&](int g) {
                 double2 ts[R], ds[R];
                 if constexpr (LT <= 6) {
-                    if (lanes) partner_sums_lanes<LT, CPLX, FAST>(v[0], a.amask[g], tid, ts[0], ds[0]);
-                    else partner_sums<LT, LGT, CPLX, FAST>(tile, v, a.amask[g], tid, ts, ds);
+                    if (lanes) do { if (!FAST && (a.cond >> g & 1u)) partner_sums_lanes<LT, CPLX, false, true>(v[0], a.amask[g], tid, ts[0], ds[0]); else partner_sums_lanes<LT, CPLX, FAST>(v[0], a.amask[g], tid, ts[0], ds[0]); } while (0);
+                    else do { if (!FAST && (a.cond >> g & 1u)) partner_sums<LT, LGT, CPLX, false, true>(tile, v, a.amask[g], tid, ts, ds); else partner_sums<LT, LGT, CPLX, FAST>(tile, v, a.amask[g], tid, ts, ds); } while (0);
                 } else {
-                    partner_sums<LT, LGT, CPLX, FAST>(tile, v, a.amask[g], tid, ts, ds);
+                    do { if (!FAST && (a.cond >> g & 1u)) partner_sums<LT, LGT, CPLX, false, true>(tile, v, a.amask[g], tid, ts, ds); else partner_sums<LT, LGT, CPLX, FAST>(tile, v, a.amask[g], tid, ts, ds); } while (0);
                 }
                 const double cr = cf(g), ci = cf(a.ga + g);
                 const double k1r = pf.br * cr, k1i = pf.bi * cr, k2r = -pf.bi * ci, k2i = pf.br * ci;
@@ -275,6 +276,7 @@ struct PersistBwdArgs {
     uint32_t amask[kPersistGroups];
     uint32_t dmask[kPersistGroups];
     int dcnt[kPersistGroups];
+    uint32_t cond;            // as in PersistArgs
     PairArgs pair;
 };
 
@@ -428,10 +430,10 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist_b
                     if (FAST || g < a.ga) {
                         double2 ts[R], ds[R];
                         if constexpr (LT <= 6) {
-                            if (lanes) partner_sums_lanes<LT, CPLX, FAST>(v[0], a.amask[g], tid, ts[0], ds[0]);
-                            else partner_sums<LT, LGT, CPLX, FAST>(tile, v, a.amask[g], tid, ts, ds);
+                            if (lanes) do { if (!FAST && (a.cond >> g & 1u)) partner_sums_lanes<LT, CPLX, false, true>(v[0], a.amask[g], tid, ts[0], ds[0]); else partner_sums_lanes<LT, CPLX, FAST>(v[0], a.amask[g], tid, ts[0], ds[0]); } while (0);
+                            else do { if (!FAST && (a.cond >> g & 1u)) partner_sums<LT, LGT, CPLX, false, true>(tile, v, a.amask[g], tid, ts, ds); else partner_sums<LT, LGT, CPLX, FAST>(tile, v, a.amask[g], tid, ts, ds); } while (0);
                         } else {
-                            partner_sums<LT, LGT, CPLX, FAST>(tile, v, a.amask[g], tid, ts, ds);
+                            do { if (!FAST && (a.cond >> g & 1u)) partner_sums<LT, LGT, CPLX, false, true>(tile, v, a.amask[g], tid, ts, ds); else partner_sums<LT, LGT, CPLX, FAST>(tile, v, a.amask[g], tid, ts, ds); } while (0);
                         }
                         const double cr = cf[g], ci = cf[a.ga + g];
                         const double k1r = pf.br * cr, k1i = pf.bi * cr, k2r = -pf.bi * ci, k2i = pf.br * ci;
@@ -528,10 +530,10 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist_b
                         double z1r = 0.0, z1i = 0.0, z2r = 0.0, z2i = 0.0;
                         double2 ts[R], ds[R];
                         if constexpr (LT <= 6) {
-                            if (lanes) partner_sums_lanes<LT, true, FAST>(mu[0], a.amask[g], tid, ts[0], ds[0]);
-                            else partner_sums<LT, LGT, true, FAST>(tile, mu, a.amask[g], tid, ts, ds);
+                            if (lanes) do { if (!FAST && (a.cond >> g & 1u)) partner_sums_lanes<LT, true, false, true>(mu[0], a.amask[g], tid, ts[0], ds[0]); else partner_sums_lanes<LT, true, FAST>(mu[0], a.amask[g], tid, ts[0], ds[0]); } while (0);
+                            else do { if (!FAST && (a.cond >> g & 1u)) partner_sums<LT, LGT, true, false, true>(tile, mu, a.amask[g], tid, ts, ds); else partner_sums<LT, LGT, true, FAST>(tile, mu, a.amask[g], tid, ts, ds); } while (0);
                         } else {
-                            partner_sums<LT, LGT, true, FAST>(tile, mu, a.amask[g], tid, ts, ds);
+                            do { if (!FAST && (a.cond >> g & 1u)) partner_sums<LT, LGT, true, false, true>(tile, mu, a.amask[g], tid, ts, ds); else partner_sums<LT, LGT, true, FAST>(tile, mu, a.amask[g], tid, ts, ds); } while (0);
                         }
 #pragma unroll
                         for (int r = 0; r < R; ++r) {

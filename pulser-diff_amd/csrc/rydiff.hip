@@ -1094,9 +1094,11 @@ int finish_runtime(Runtime& rt, double lo, double hi) {
         rt.max_step_factors = std::max(rt.max_step_factors, f);
     }
     fill_group_args(pl, rt.garg);
-    if (pl.ga.flagged) {  // conditioned flips (three-level registers): the generic one-amplitude-per-thread kernels, any size
+    if (pl.ga.flagged) {
+        // conditioned flips (three-level registers): the one-launch kernels up to 12 qubits (their tile IS the register), beyond
+        // that the generic one-amplitude-per-thread kernels — never the unrolled global-drive or the chained tile kernels
         rt.generic_direct = true;
-        rt.variant = 1;
+        if (pl.N > kTileBits) rt.variant = 1;
     }
     rt.parg.n = pl.n_pair;
     for (int t = 0; t < pl.n_pair; ++t) {
@@ -1757,7 +1759,7 @@ template <int LT, bool CPLX>
 int launch_persist_t(const PersistArgs& pa, int B, hipStream_t stream) {
     constexpr int LGT = LT < 10 ? LT : 10;
     const dim3 block(LGT < 6 ? 64 : (1 << LGT));
-    if (pa.ga == 1 && pa.gd <= 1 && pa.amask[0] == (1u << LT) - 1u && pa.pair.n == 0)
+    if (pa.ga == 1 && pa.gd <= 1 && pa.amask[0] == (1u << LT) - 1u && pa.pair.n == 0 && pa.cond == 0)
         hipLaunchKernelGGL((k_persist<LT, LGT, CPLX, true, true>), dim3(B), block, 0, stream, pa);
     else if (pa.ga <= 2 && pa.gd <= 2)
         hipLaunchKernelGGL((k_persist<LT, LGT, CPLX, true, false, 2>), dim3(B), block, 0, stream, pa);
@@ -1771,7 +1773,7 @@ int launch_persist_t(const PersistArgs& pa, int B, hipStream_t stream) {
 
 template <int LT, bool CPLX>
 int launch_lanes_fwd_t(const PersistArgs& pa, int B, hipStream_t stream) {
-    if (pa.ga == 1 && pa.gd <= 1 && pa.amask[0] == (1u << LT) - 1u && pa.pair.n == 0)
+    if (pa.ga == 1 && pa.gd <= 1 && pa.amask[0] == (1u << LT) - 1u && pa.pair.n == 0 && pa.cond == 0)
         hipLaunchKernelGGL((k_lanes_fwd<LT, CPLX, true>), dim3(B), dim3(64), 0, stream, pa);
     else if (pa.ga <= 2 && pa.gd <= 2)
         hipLaunchKernelGGL((k_lanes_fwd<LT, CPLX, false, 2>), dim3(B), dim3(64), 0, stream, pa);
@@ -1817,7 +1819,7 @@ int launch_persist(int variant, int N, const PersistArgs& pa, int B, hipStream_t
 template <int LT, bool CPLX>
 int launch_persist_bwd_t(const PersistBwdArgs& pa, int B, hipStream_t stream) {
     constexpr int LGT = LT < 10 ? LT : 9;  // 1024+ amplitudes: 512 threads, so the accumulators stay in registers
-    if (pa.ga == 1 && pa.gd <= 1 && pa.amask[0] == (1u << LT) - 1u && pa.pair.n == 0)
+    if (pa.ga == 1 && pa.gd <= 1 && pa.amask[0] == (1u << LT) - 1u && pa.pair.n == 0 && pa.cond == 0)
         hipLaunchKernelGGL((k_persist_bwd<LT, LGT, CPLX, true>), dim3(B), dim3(LGT < 6 ? 64 : (1 << LGT)), 0, stream, pa);
     else if (pa.ga <= 2 && pa.gd <= 2)
         hipLaunchKernelGGL((k_persist_bwd<LT, LGT, CPLX, false, 2>), dim3(B), dim3(LGT < 6 ? 64 : (1 << LGT)), 0, stream, pa);
@@ -1830,7 +1832,7 @@ int launch_persist_bwd_t(const PersistBwdArgs& pa, int B, hipStream_t stream) {
 template <int LT, bool CPLX>
 int launch_lanes_bwd_t(const PersistBwdArgs& pa, int B, hipStream_t stream) {
     if (pa.tape_full) {  // every factor input is on the tape: one descending walk, nothing recomputed
-        if (pa.ga == 1 && pa.gd <= 1 && pa.amask[0] == (1u << LT) - 1u && pa.pair.n == 0)
+        if (pa.ga == 1 && pa.gd <= 1 && pa.amask[0] == (1u << LT) - 1u && pa.pair.n == 0 && pa.cond == 0)
             hipLaunchKernelGGL((k_lanes_bwd_tape<LT, CPLX, true>), dim3(B), dim3(64), 0, stream, pa);
         else if (pa.ga <= 2 && pa.gd <= 2)
             hipLaunchKernelGGL((k_lanes_bwd_tape<LT, CPLX, false, 2>), dim3(B), dim3(64), 0, stream, pa);
@@ -1839,7 +1841,7 @@ int launch_lanes_bwd_t(const PersistBwdArgs& pa, int B, hipStream_t stream) {
         LAUNCH_CHECK();
         return RYDIFF_OK;
     }
-    if (pa.ga == 1 && pa.gd <= 1 && pa.amask[0] == (1u << LT) - 1u && pa.pair.n == 0)
+    if (pa.ga == 1 && pa.gd <= 1 && pa.amask[0] == (1u << LT) - 1u && pa.pair.n == 0 && pa.cond == 0)
         hipLaunchKernelGGL((k_lanes_bwd<LT, CPLX, true>), dim3(B), dim3(64), 0, stream, pa);
     else if (pa.ga <= 2 && pa.gd <= 2)
         hipLaunchKernelGGL((k_lanes_bwd<LT, CPLX, false, 2>), dim3(B), dim3(64), 0, stream, pa);
@@ -2076,6 +2078,7 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
         pa.gd = pl.gd.n;
         pa.pair = rt.parg;
         for (int g = 0; g < pl.ga.n; ++g) pa.amask[g] = pl.ga.amp_index_mask[g];
+        pa.cond = pl.ga.flagged;
         for (int g = 0; g < pl.gd.n; ++g) {
             pa.dmask[g] = pl.gd.amp_index_mask[g];
             pa.dcnt[g] = pl.gd.count[g];
@@ -2258,6 +2261,7 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
         pa.gd = pl.gd.n;
         pa.pair = rt.parg;
         for (int g = 0; g < pl.ga.n; ++g) pa.amask[g] = pl.ga.amp_index_mask[g];
+        pa.cond = pl.ga.flagged;
         for (int g = 0; g < pl.gd.n; ++g) {
             pa.dmask[g] = pl.gd.amp_index_mask[g];
             pa.dcnt[g] = pl.gd.count[g];

@@ -15,12 +15,14 @@ from tests.test_host_logic import _three_level_emulator
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n_qubits,batch", [(4, 1), (6, 3), (14, 1)])
-def test_conditioned_flips_and_ones_counting_terms_through_the_c_abi(cuda_device, n_qubits, batch):
+@pytest.mark.parametrize("n_qubits,batch,variant,family", [(4, 1, 0, "lanes"), (6, 3, 0, "lanes"), (6, 3, 8, "persistent"), (8, 2, 0, "persistent"),
+                                                          (10, 1, 0, "persistent"), (12, 1, 0, "persistent"), (6, 3, 1, "direct"), (14, 1, 0, "direct")])
+def test_conditioned_flips_and_ones_counting_terms_through_the_c_abi(cuda_device, n_qubits, batch, variant, family):
     """Random structured problems with the two new term flags straight through `evolve`: states, <O>(t) and all five gradient kinds
-    against the explicit matrix of the SAME term list (tests/helpers.py:dense_from_structured_terms) under the KRYLOV_SE map.
-    14 qubits: forward only, against the native run of the equivalent problem restricted ... (dense 2^14 is out of reach) — there the
-    check is norm conservation and that the unused codes stay empty."""
+    against the explicit matrix of the SAME term list (tests/helpers.py:dense_from_structured_terms) under the KRYLOV_SE map, on
+    every kernel family that takes conditioned flips: the one-wave lane kernels, the one-workgroup persistent kernels (variant 8
+    forces them at 6 qubits; 12 qubits = persistent forward + direct adjoint) and the generic direct kernels.  14 qubits (dense
+    2^14 is out of reach): norm conservation and the unused codes staying empty."""
     from pulser_diff_amd.solver import ProblemSpec, SolverType, evolve
 
     gen = torch.Generator().manual_seed(77 + n_qubits)
@@ -42,15 +44,21 @@ def test_conditioned_flips_and_ones_counting_terms_through_the_c_abi(cuda_device
     psi = (psi / psi.norm(dim=1, keepdim=True)).to(cuda_device)
     obs = torch.rand(1, 2**n_qubits, generator=gen, dtype=torch.float64).to(cuda_device)
     spec = ProblemSpec(n_qubits, dt, ns, amp_masks, det_masks, solver=SolverType.KRYLOV_SE, store_states=True,
-                       amp_conditioned=amp_cond, det_ones=det_ones)
-    if n_qubits > 8:
+                       amp_conditioned=amp_cond, det_ones=det_ones, kernel_variant=variant)
+    if n_qubits > 10:  # the dense reference is out of reach: structure checks, and the other kernel family as the reference
         with torch.no_grad():
             states, expect = evolve(amp, det, u, tsave, psi, spec, obs)
-        assert dict(spec.options["_last_stats"])["kernel_family"] == "direct"
+        assert dict(spec.options["_last_stats"])["kernel_family"] == family
         assert (states.abs().square().sum(-1) - 1).abs().max() < 1e-11
         invalid = torch.ones(2**n_qubits, dtype=torch.bool)
         invalid[valid] = False
         assert states[..., invalid.to(cuda_device)].abs().max() == 0.0
+        if family != "direct":
+            direct = ProblemSpec(n_qubits, dt, ns, amp_masks, det_masks, solver=SolverType.KRYLOV_SE, store_states=True,
+                                 amp_conditioned=amp_cond, det_ones=det_ones, kernel_variant=1)
+            with torch.no_grad():
+                ref, ref_e = evolve(amp, det, u, tsave, psi, direct, obs)
+            assert (states - ref).abs().max() < 1e-11 and (expect - ref_e).abs().max() < 1e-11
         return
     leaves = [amp.clone().requires_grad_(True), det.clone().requires_grad_(True), u.clone().requires_grad_(True),
               tsave.clone().requires_grad_(True), psi.clone().requires_grad_(True)]
@@ -58,7 +66,7 @@ def test_conditioned_flips_and_ones_counting_terms_through_the_c_abi(cuda_device
     w = torch.linspace(0.4, 1.3, len(tsave), dtype=torch.float64, device=cuda_device)
     loss = (expect[0] * w[:, None]).sum() + (states[-1, :, 3].real * 0.7).sum()
     loss.backward()
-    assert dict(spec.options["_last_stats"])["kernel_family"] == "direct"
+    assert dict(spec.options["_last_stats"])["kernel_family"] == family  # one wave / one workgroup / one amplitude per thread
 
     # reference: dense matrix of the same term list, KRYLOV_SE map (right-endpoint H), torch autograd
     ref_leaves = [t.detach().cpu().clone().requires_grad_(True) for t in leaves]
@@ -94,7 +102,8 @@ def test_three_level_sequence_through_the_emulator(cuda_device, solver_name, loc
     sim, coords = _three_level_emulator(compute_device="cuda", local_raman=local_raman)
     ham = sim._hamiltonian
     res = sim.run(solver=getattr(SolverType, solver_name))
-    assert res.solver_stats["kernel_family"] == "direct"
+    assert res.solver_stats["kernel_family"] in ("lanes", "persistent")  # 3 atoms = 6 qubits: one launch per sweep (one wave, or one
+    # workgroup when the local Raman pulses make more than four detuning groups)
     states = res.states.detach().cpu()  # (n_t, 27, 1)
     assert states.shape[1:] == (27, 1)
     assert (states.abs().square().sum(1) - 1).abs().max() < 1e-10
