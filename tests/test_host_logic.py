@@ -500,3 +500,13 @@ def test_three_level_measurement_weights():
                     ref[4 * (i == one) + 2 * (j == one) + (k == one)] += p[i, j, k]
         assert (w - ref).abs().max() < 1e-15 and abs(float(w.sum()) - 1) < 1e-14
         assert set(res.get_samples(50)) <= {format(i, "03b") for i in range(8)}
+
+
+def test_integration_document_mirrors_the_abi_structs():
+    """INTEGRATION.md shows the ctypes stub a pulser-diff maintainer would add: its struct mirrors must list the header's fields in order."""
+    txt = (ROOT / "INTEGRATION.md").read_text()
+    problem = txt[txt.index("class RydProblem(ctypes.Structure)"):txt.index("class RydPlanInfo(ctypes.Structure)")]
+    assert re.findall(r'\("(\w+)",', problem) == [f[0] for f in _native.RydProblem._fields_]
+    info = txt[txt.index("class RydPlanInfo(ctypes.Structure)"):]
+    info = info[:info.index("]")]
+    assert re.findall(r'\("(\w+)",', info) == [f[0] for f in _native.RydPlanInfo._fields_]
