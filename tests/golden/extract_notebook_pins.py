@@ -68,12 +68,16 @@ def _named_parameters(txt):
     return out
 
 
-def _optimised_run(cells, loss_cell, final_cell, what):
+def _optimised_run(cells, loss_cell, final_cell, what, init_cell=None):
     loss_txt, final_txt = _out_text(cells[loss_cell]), _out_text(cells[final_cell])
     best = re.search(r"Best loss: (" + _FLOAT + r") after (\d+) epochs", loss_txt)
     fid = re.search(what + r" fidelity: (" + _FLOAT + r")%", final_txt)
     first = re.search(r"\[t=0\]loss: (" + _FLOAT + r")", loss_txt)
-    return {"first_loss": float(first.group(1)), "best_loss": float(best.group(1)), "best_epoch": int(best.group(2)), "printed_fidelity_percent": float(fid.group(1)),
+    trace = {int(k): float(v) for k, v in re.findall(r"\[t=(\d+)\]loss: (" + _FLOAT + r")", loss_txt)}
+    extra = {"loss_trace": trace}
+    if init_cell is not None:  # the shaped-pulse runs print their (random) INITIAL parameters too: the trace becomes reproducible
+        extra["initial_parameters"] = _named_parameters(_out_text(cells[init_cell]))
+    return {**extra, "first_loss": float(first.group(1)), "best_loss": float(best.group(1)), "best_epoch": int(best.group(2)), "printed_fidelity_percent": float(fid.group(1)),
             "parameters": _named_parameters(final_txt)}
 
 
@@ -100,9 +104,9 @@ def main():
     # KA-6..KA-8: final parameters + best loss + printed fidelity of the two optimal-control notebooks
     sp = json.loads(NB.with_name("state_preparation.ipynb").read_text())["cells"]
     go = json.loads(NB.with_name("gate_optimization.ipynb").read_text())["cells"]
-    pins["ka6_state_preparation"] = _optimised_run(sp, 10, 12, "State")
+    pins["ka6_state_preparation"] = _optimised_run(sp, 10, 12, "State", init_cell=8)
     pins["ka7_gate_constant_pulses"] = _optimised_run(go, 13, 16, "Gate")
-    pins["ka8_gate_pulse_shape"] = _optimised_run(go, 25, 28, "Gate")
+    pins["ka8_gate_pulse_shape"] = _optimised_run(go, 25, 28, "Gate", init_cell=23)
     assert [len(v) for v in pins["ka6_state_preparation"]["parameters"].values()] == [30, 30]
     assert len(pins["ka7_gate_constant_pulses"]["parameters"]) == 24
     assert [len(v) for v in pins["ka8_gate_pulse_shape"]["parameters"].values()] == [20, 20]

@@ -198,3 +198,32 @@ def test_state_preparation_descends(cuda_device):
         model.update_sequence()
         losses.append(float(loss.detach()))
     assert losses[0] > 0.9 and min(losses) < 0.5 * losses[0], losses
+
+
+@pytest.mark.parametrize("which", ["state", "gate"])
+def test_training_traces_replayed_from_the_printed_initial_parameters(cuda_device, which):
+    """The two shaped-pulse notebooks print their (random) INITIAL parameters in full next to the loss every 50 epochs (6 decimals).
+    Replaying the notebooks' loop — Adam lr 5, cosine annealing with warm restarts on plateaus (examples/optimal_control_loop.py) —
+    from those parameters, with the native adjoint supplying 60 / 40 gradients per epoch, must land on the printed losses after 50,
+    100, 150 and 200 epochs: an end-to-end pin of the GRADIENTS over hundreds of optimiser steps (DP5_SE, custom waveforms through
+    interpolate_sine, level-60 C6; the gate run evolves 16 columns at once).  Observed: 2.3e-5 / 3e-6; the residual is the reference's
+    own Dormand-Prince error plus the 4-decimal print of the initial parameters."""
+    import sys
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "examples"))
+    from optimal_control_loop import train
+
+    if which == "state":
+        pin, tol = PINS["ka6_state_preparation"], 1.0e-4
+        init = pin["initial_parameters"]
+        model = _shaped_model(_device(6.28), 6, 7.0, 30, 0.02, torch.tensor(init["amp_custom_0"]), torch.tensor(init["det_custom_0"]))
+        loss_of = lambda m: _state_infidelity(m, 6)  # noqa: E731
+    else:
+        pin, tol = PINS["ka8_gate_pulse_shape"], 2.0e-5
+        init = pin["initial_parameters"]
+        model = _shaped_model(_device(12.566370614359172), 4, 6.5, 20, 0.05, torch.tensor(init["amp_custom_0"]),
+                              torch.tensor(init["det_custom_0"]), initial_state=torch.eye(16))
+        loss_of = lambda m: _gate_infidelity(m, 4)  # noqa: E731
+    _, history = train(model, loss_of, 201, lr=5.0, log_every=0)
+    for epoch in (0, 50, 100, 150, 200):
+        assert abs(history[epoch] - pin["loss_trace"][str(epoch)]) < tol, (epoch, history[epoch], pin["loss_trace"][str(epoch)])
