@@ -206,11 +206,11 @@ def _chain(n, spacing):
     return torch.tensor([[spacing * (i - (n - 1) / 2), 0.0] for i in range(n)], dtype=torch.float64)
 
 
-def _shaped_pulse(pin, n_param, duration, gamma, max_amp, max_det):
+def _shaped_pulse(pin, n_param, duration, gamma, max_amp, max_det, which="parameters"):
     """The notebooks' custom_wf_amp / custom_wf_det, in float32 like their leaves."""
     mat = R.sine_interpolation_matrix(n_param, duration)
-    amp = mat @ (max_amp * torch.sigmoid(gamma * torch.tensor(pin["parameters"]["amp_custom_0"])))
-    det = mat @ (max_det * torch.tanh(gamma * torch.tensor(pin["parameters"]["det_custom_0"])))
+    amp = mat @ (max_amp * torch.sigmoid(gamma * torch.tensor(pin[which]["amp_custom_0"])))
+    det = mat @ (max_det * torch.tanh(gamma * torch.tensor(pin[which]["det_custom_0"])))
     return R.concat_pulses([(amp, det, 0.0)])
 
 
@@ -275,3 +275,17 @@ def test_ka8_four_qubit_gate_with_shaped_pulse():
     loss = _gate_infidelity(_hadamards(4), gate)
     assert abs(loss - pin["best_loss"]) < 2e-6
     assert f"{100 * (1 - loss):.2f}" == f"{pin['printed_fidelity_percent']:.2f}"
+
+
+def test_first_printed_losses_at_the_printed_initial_parameters():
+    """Both shaped-pulse notebooks also print their random INITIAL parameters: the first printed loss (6 decimals) is one more
+    forward pin each — the gate's 0.906707 is far from trivial.  (The full traces, i.e. the gradients over hundreds of optimiser
+    steps, are replayed on the GPU: tests/test_gpu_optimal_control.py.)"""
+    pin = PINS["ka8_gate_pulse_shape"]
+    seq = _shaped_pulse(pin, 20, 1100, 0.05, 12, 12, which="initial_parameters")
+    gate = _final_dp5(seq, _chain(4, 6.5), np.eye(16, dtype=complex))
+    assert abs(_gate_infidelity(_hadamards(4), gate) - pin["loss_trace"]["0"]) < 5e-6
+    pin = PINS["ka6_state_preparation"]
+    seq = _shaped_pulse(pin, 30, 1100, 0.02, 12, 6, which="initial_parameters")
+    final = _final_dp5(seq, _chain(6, 7.0), R.all_ground_state(6).numpy())
+    assert abs((1 - abs(final[0, 0]) ** 2) - pin["loss_trace"]["0"]) < 1e-6
