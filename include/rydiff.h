@@ -116,6 +116,8 @@ typedef struct RydProblem {
      *   7 automatic, but three tile layouts wherever they are legal (21 <= N <= 28)
      *   8 automatic, but the LDS-tile persistent kernels also up to 6 qubits (instead of the one-wave lane kernels)
      *  10 chained passes with trajectory-per-XCD placement forced (L2-resident trajectories)
+     *  11 automatic, but TWO tile layouts up to 24 qubits (32- / 16-byte runs in the second layout at 23 / 24 qubits)
+     *  12 automatic, but tiles in plain workgroup order (no line-sharing swizzle where a layout's runs are shorter than 128 bytes)
      * "automatic" takes the one-launch sweeps up to 12 qubits, the direct kernels while few tiles are in flight
      * (B * 2^N <= 2^18, with gradients 2^19) and the chained passes beyond.  Results do not depend on the variant beyond rounding. */
     int32_t kernel_variant;

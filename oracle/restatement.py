@@ -669,12 +669,14 @@ def structured_matvec_torch(terms: HamTerms, diag: Tensor, coeffs: list, psi: Te
 
 
 def krylov_map_matrix_free_torch(terms: HamTerms, psi0: Tensor, tsave: Tensor, tol: float = 1e-17,
-                                 checkpoint: bool = False) -> Tensor:
+                                 checkpoint: bool = False, on_state: Callable | None = None) -> Tensor:
     """Same map as krylov_map_dense — psi_{k+1} = exp(-i H(t_{k+1}) (t_{k+1} - t_k)) psi_k — evaluated matrix-free by the
     Taylor series of the exponential (terms until below `tol` relative), in torch: autograd through it gives the exact
     gradients of the discrete map w.r.t. the coefficient arrays, U_ij, tsave and psi0 for registers far beyond dense H.
     A different numerical route from the product-form Chebyshev polynomial of the native library and from Lanczos.
-    psi0: (dim,) or (dim, B).  checkpoint=True re-computes each step in the backward pass (memory of one step)."""
+    psi0: (dim,) or (dim, B).  checkpoint=True re-computes each step in the backward pass (memory of one step).
+    on_state(k, psi_k): called with every state as it is produced and ONLY the final state is returned (long trajectories of
+    large registers: the stack of all states would not fit)."""
     n = terms.n_qubits
     masks = _bit_masks_torch(n)
     occ = occupation_table(n)
@@ -702,15 +704,20 @@ def krylov_map_matrix_free_torch(terms: HamTerms, psi0: Tensor, tsave: Tensor, t
     flat = [c for c, _ in terms.amp_terms()] + [c for c, _ in terms.det_terms()]
     psi = psi0
     out = [psi]
+    if on_state is not None:
+        on_state(0, psi)
     for k in range(len(tsave) - 1):
         if checkpoint:
             from torch.utils.checkpoint import checkpoint as ckpt
 
-            psi = ckpt(step, psi, tsave[k + 1], tsave[k], udiag, *flat, use_reentrant=False)
+            psi = ckpt(step, psi, tsave[k + 1], tsave[k], udiag, *flat, use_reentrant=True)  # (the non-reentrant flavour keeps ~1.5 GiB per 20-qubit step alive in torch 2.10)
         else:
             psi = step(psi, tsave[k + 1], tsave[k], udiag, *flat)
-        out.append(psi)
-    return torch.stack(out)
+        if on_state is not None:
+            on_state(k + 1, psi)
+        else:
+            out.append(psi)
+    return psi if on_state is not None else torch.stack(out)
 
 
 # Dormand-Prince 5(4) tableau (pyqtorch DP5_SE restated: adaptive, RHS -i H(t) psi)

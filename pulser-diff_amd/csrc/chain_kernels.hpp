@@ -74,6 +74,12 @@ struct ChainArgs {
     // workgroup w of row y works on tile w / 8 of trajectory 8 y + w % 8, so that ALL tiles of one trajectory, in every
     // layout, run on one XCD and its vectors stay in that L2 from pass to pass (no fabric traffic).  0: grid (tiles, B).
     int xcd_place;
+    // Line-sharing tiles on one XCD (speed only): in a layout whose low run is shorter than a 128-byte line (lo < 3: 22 qubits, and
+    // the forced two-layout variants beyond) 2^(3-lo) CONSECUTIVE tiles own interleaved pieces of the same lines.  With the plain
+    // grid they run on different XCDs (workgroup id % 8), so every line is fetched into 2^(3-lo) L2s and written back in pieces.
+    // tile_swz = 3 - lo maps workgroup w to tile  (w & ~(8 G - 1)) | (w % 8) * G | (w / 8) % G,  G = 2^tile_swz: the G tiles of a
+    // line run on ONE XCD, 8 workgroup ids apart — the second tile's loads hit the line the first one fetched.  0: identity.
+    int tile_swz;
     int b_first, b_count;              // this launch covers trajectories [b_first, b_first + b_count)
     int resident;                      // launch the RES instantiation: plain loads / stores (lines stay in the XCD's L2)
     // backward (adjoint) mode only: u/p/v/q are cotangents, gamma/beta above are already conjugated
@@ -315,7 +321,11 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
         }
     };
     const unsigned tid = threadIdx.x;
-    const unsigned t = a.xcd_place ? (blockIdx.x >> 3) : blockIdx.x;                       // tile of the trajectory
+    unsigned t = a.xcd_place ? (blockIdx.x >> 3) : blockIdx.x;                             // tile of the trajectory
+    if (a.tile_swz) {
+        const unsigned w = blockIdx.x, G = 1u << a.tile_swz;
+        t = (w & ~(8u * G - 1u)) | ((w & 7u) << a.tile_swz) | ((w >> 3) & (G - 1u));
+    }
     const unsigned bl = a.xcd_place ? (blockIdx.y * 8u + (blockIdx.x & 7u)) : blockIdx.y;  // trajectory within the launch
     if (bl >= unsigned(a.b_count)) return;                                                 // ragged last row of 8
     const unsigned bt = unsigned(a.b_first) + bl;                                          // trajectory

@@ -385,10 +385,10 @@ inline size_t carve(Plan& pl, int tape_mode, bool need_backward, int chain_slots
     pl.off_buf1 = take(pl.state_bytes);
     pl.off_pp0 = take(pl.state_bytes);  // partial vectors of the chained passes
     pl.off_pp1 = take(pl.state_bytes);
-    // split interaction diagonal for the two tile layouts: utt[2][4096] + vr[2][tiles][16]
-    {   // (sharded runs index the table by the GLOBAL tile: 2^(N-12) rows)
+    // split interaction diagonal for the tile layouts: utt[3][2^LT] + vr[3][tiles][16], sized for the largest tile (2^13 amplitudes)
+    {   // (sharded runs index the table by the GLOBAL tile: 2^(N-LT) rows)
         const size_t gdim = size_t(1) << pl.N;
-        pl.off_split = take(3 * (4096 + (gdim >> 11 ? (gdim >> 11) : 1) * 16) * sizeof(double));  // up to three tile layouts
+        pl.off_split = take(3 * (8192 + (gdim >> 11 ? (gdim >> 11) : 1) * 16) * sizeof(double));  // up to three tile layouts
     }
     pl.off_ptable = take(pl.ptable_bytes);
     if (pl.ptable_bytes) {

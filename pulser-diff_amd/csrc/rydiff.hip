@@ -950,13 +950,15 @@ struct LayoutDesc {
     uint32_t bits;  // amplitude-index bits covered by the tile
 };
 
-// force_three: kernel variant 7 — three layouts wherever they are legal (A/B tests)
-int chain_layout_count(int N, bool force_three) {
-    if (N >= 23 || (force_three && N >= 21)) return 3;
+// force_three (layout mode): 0 automatic; 1 = kernel variant 7 — three layouts wherever they are legal; 2 = kernel variant 11 — two
+// layouts up to 24 qubits (layout B then has runs of 32 / 16 bytes at 23 / 24 qubits).  Both for A/B tests.
+int chain_layout_count(int N, int force_three) {
+    if (force_three == 2 && N <= 24) return 2;
+    if (N >= 23 || (force_three == 1 && N >= 21)) return 3;
     return 2;
 }
 
-LayoutDesc chain_layout(int N, int which, bool force_three) {
+LayoutDesc chain_layout(int N, int which, int force_three) {
     LayoutDesc d{};
     const bool three = chain_layout_count(N, force_three) == 3;
     if (which == 0) {  // A
@@ -968,8 +970,8 @@ LayoutDesc chain_layout(int N, int which, bool force_three) {
         d.hb = three ? 8 : N - kTileBits;
         d.lo = kTileBits - d.hb;
     } else {  // C (three-layout mode only)
-        d.hs = 20;
-        d.hb = N - 20;
+        d.hs = kTileBits + 8;
+        d.hb = N - d.hs;
         d.lo = kTileBits - d.hb;
     }
     d.bits = ((1u << d.lo) - 1u) | (((1u << d.hb) - 1u) << d.hs);
@@ -993,7 +995,8 @@ struct Runtime {
     // RydProblem.kernel_variant decoded (include/rydiff.h); nothing about the kernel choice lives outside this struct
     int variant = 0;              // 0 auto | 1 direct | 2..4 chained tiles | 8 auto with LDS-tile kernels below 7 qubits
     bool generic_direct = false;  // variant 9: direct kernels without the unrolled global-drive instantiations
-    bool force_three = false;     // variant 7: three tile layouts wherever they are legal
+    bool plain_tile_order = false;  // variant 12: no line-sharing tile swizzle (ChainArgs.tile_swz)
+    int force_three = 0;          // 1: variant 7, three tile layouts wherever they are legal; 2: variant 11, two layouts up to 24 qubits
     bool force_xcd = false;       // variant 10: trajectory-per-XCD placement of the chained tiles forced
     int chain_lgt = 9;            // log2(threads per tile workgroup) of explicitly chosen chained variants
     // state-sharded run: where the partner slabs arrive and who moves them (RydProblem.shard_recv / shard_exchange)
@@ -1007,11 +1010,12 @@ struct Runtime {
 // RydProblem.kernel_variant -> Runtime (include/rydiff.h lists the values)
 int decode_variant(const RydProblem* p, Runtime& rt) {
     int v = p->kernel_variant;
-    if (v < 0 || v > 10 || v == 5 || v == 6) return fail(RYDIFF_EINVAL, "kernel_variant must be 0..4 or 7..10");
+    if (v < 0 || v > 12 || v == 5 || v == 6) return fail(RYDIFF_EINVAL, "kernel_variant must be 0..4 or 7..12");
     rt.generic_direct = v == 9;
     if (v == 9) v = 1;
-    rt.force_three = v == 7;
-    if (v == 7) v = 0;
+    rt.force_three = v == 7 ? 1 : (v == 11 ? 2 : 0);
+    rt.plain_tile_order = v == 12;
+    if (v == 7 || v == 11 || v == 12) v = 0;
     rt.force_xcd = v == 10;
     if (v == 10) v = 0;
     rt.variant = v;
@@ -1409,7 +1413,7 @@ struct KernelStep {
     int sta;
 };
 
-void chain_schedule(int N, bool force_three, int F, std::vector<KernelStep>& ks) {
+void chain_schedule(int N, int force_three, int F, std::vector<KernelStep>& ks) {
     ks.clear();
     if (chain_layout_count(N, force_three) == 2) {
         for (int k = 0; k <= F; ++k)
@@ -1601,6 +1605,7 @@ int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, const BatchSl
         }
     }
     const unsigned tiles = unsigned(pl.dim >> kTileBits);
+    if (X.lo < 3 && !bs.xcd && !rt.plain_tile_order && tiles % (8u << (3 - X.lo)) == 0) ca.tile_swz = 3 - X.lo;
     const bool cplx = (rt.flags & 1) != 0 || (cs.bwd && !rt.real_amp_grad);
     // auto: 1024 threads per tile for the forward passes, 512 for the (register-hungrier) adjoint passes
     // (the real-drive adjoint, without the signed sums, fits 1024 threads too: measured 2710 -> 2767 steps/s on C3)

@@ -9,6 +9,9 @@ outputs, so the GPU tests (tests/test_gpu_baseline_fixtures.py) feed the native 
   baseline_c2       12-qubit chain, Blackman(1000 ns, 2 pi) + Ramp(-5 -> +5), 1000 steps: <sum Z>(t_k), |psi_T|, 16 amplitudes
   baseline_c4       16-qubit 4x4, two parameter sets of the bench template (4 segments x 25 ns): <sum Z>(t_k), 16 amplitudes each
   baseline_c3       20-qubit 4x5, bench.py's own first parameter set, first 10 of its 1000 steps: <sum Z>(t_k), 16 amplitudes
+  baseline_c3_full  C3 at FULL length (round 3): all 1000 steps of bench.py's first parameter set on the 20-qubit 4x5 register in ONE
+                    checkpointed autograd run of the matrix-free map: <sum Z>(t_k) at all 1001 save points, |psi_T|, 16 amplitudes
+                    at T/2 and T, and the 8 parameter gradients of <sum Z>(T) through all 1000 steps (about 1.5 h on 8 cores)
   baseline_c3_grad  20-qubit 4x5, the same parameter set on a compressed pulse (4 segments x 3 ns): the 8 parameter gradients of
                     <sum Z>(T) by autograd through the oracle's matrix-free map
   grad_dense_n8/n10 all five gradient kinds (amplitude tables Re/Im, detuning tables, U_ij, tsave, psi0) by autograd through the
@@ -131,6 +134,44 @@ def make_c3_grad():
                         coords=coords.numpy(), tsave=tsave.numpy(), z_t=z.detach().numpy(), g_omega=omega.grad.numpy(), g_delta=delta.grad.numpy())
 
 
+def make_c3_full(steps=1000, name="baseline_c3_full"):
+    """The headline workload end to end.  One pass: every step is a checkpointed autograd node (memory: one 16 MiB state per step
+    + one step's Taylor terms), <sum Z> and the probe amplitudes are read off as the states go by, the loss is <sum Z>(T)."""
+    n, seg_len = 20, 250
+    omega0, delta0 = bench_parameter_sets(1)
+    omega = omega0[0].clone().requires_grad_(True)
+    delta = delta0[0].clone().requires_grad_(True)
+    coords = grid_coords(4, 5)
+    seq = segment_sequence(omega, delta, seg_len)
+    terms = R.build_terms(seq, coords, 1.0)
+    tsave = R.evaluation_times(seq.tot_duration, 1.0)[: steps + 1]
+    zd = R.total_magnetization_diag(n)
+    idx = AMP_IDX(2**n)
+    psi0 = R.all_ground_state(n)[:, 0]
+    z_t, amps_mid = [], []
+    t0 = time.time()
+    with torch.no_grad():  # first step against the oracle's Lanczos map (an independent route), as forward_checks does
+        one = R.krylov_map_matrix_free_torch(terms, psi0, tsave[:2])[1].numpy()
+        ref = R.krylov_map_matrix_free(terms, psi0.numpy()[:, None], tsave.numpy()[:2], tol=1e-14)[1, :, 0]
+        assert np.abs(one - ref).max() < 1e-11
+
+    def on_state(k, st):
+        z_t.append(float(((st.detach().abs() ** 2) * zd).sum()))
+        if k == steps // 2:
+            amps_mid.append(st.detach().numpy()[idx].copy())
+        if k % 50 == 0:
+            print(f"   step {k}: <sum Z> = {z_t[-1]:+.12f}   {time.time() - t0:.0f} s", flush=True)
+
+    psi = R.krylov_map_matrix_free_torch(terms, psi0, tsave, checkpoint=True, on_state=on_state)
+    loss = ((psi.abs() ** 2) * zd).sum()
+    loss.backward()
+    print(f"   backward done {time.time() - t0:.0f} s", flush=True)
+    np.savez_compressed(OUT / f"{name}.npz", omega=omega.detach().numpy(), delta=delta.detach().numpy(), seg_len=seg_len,
+                        coords=coords.numpy(), tsave=tsave.numpy(), z_t=np.array(z_t), norm_T=float(torch.linalg.vector_norm(psi.detach())),
+                        amp_idx=idx, amps_T=psi.detach().numpy()[idx], amps_mid=amps_mid[0],
+                        g_omega=omega.grad.numpy(), g_delta=delta.grad.numpy())
+
+
 def leaf_terms(terms):
     o = R.HamTerms(terms.n_qubits, terms.u_pairs.clone().requires_grad_(True), terms.amp_coeff.clone().requires_grad_(True),
                    terms.det_coeff.clone().requires_grad_(True), terms.dt, terms.n_samples, terms.amp_targets, terms.det_targets)
@@ -200,6 +241,7 @@ MAKERS = {
     "baseline_c4": make_c4,
     "baseline_c3": make_c3,
     "baseline_c3_grad": make_c3_grad,
+    "baseline_c3_full": make_c3_full,
     "grad_dense_n8": lambda: gradient_fixture("grad_dense_n8", 8, 808, R.krylov_map_dense),
     "grad_dense_n10": lambda: gradient_fixture("grad_dense_n10", 10, 1010, R.krylov_map_dense),
     "grad_mf_n14": lambda: gradient_fixture("grad_mf_n14", 14, 1414, lambda o, p, t: R.krylov_map_matrix_free_torch(o, p, t), fd_check=True),
@@ -208,7 +250,7 @@ MAKERS = {
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    for name in (sys.argv[1:] or list(MAKERS)):
+    for name in (sys.argv[1:] or [m for m in MAKERS if m != "baseline_c3_full"]):  # the full-length run only when named
         t0 = time.time()
         MAKERS[name]()
         print(f"{name}: {time.time() - t0:.1f} s, {(OUT / (name + '.npz')).stat().st_size / 1024:.1f} KiB", flush=True)

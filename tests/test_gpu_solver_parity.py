@@ -246,10 +246,12 @@ def _run_variant(variant, terms, tsave, psi_bd, device, obs, grads=True, batch_t
 
 
 @pytest.mark.parametrize("n_qubits,local,variant", [(13, True, 2), (14, False, 3), (16, True, 4), (17, True, 2), (20, False, 2),
-                                                     (22, False, 4), (21, True, 7), (22, True, 7), (23, True, 0), (24, False, 0), (25, True, 0)])
+                                                     (22, False, 4), (21, True, 7), (22, True, 7), (23, True, 0), (24, False, 0), (25, True, 0),
+                                                     (22, True, 0), (22, False, 12), (23, False, 11), (24, True, 11)])
 def test_chained_tile_kernels_match_direct_kernels(cuda_device, n_qubits, local, variant):
     """A/B on the GPU: the chained LDS-tile kernels (two tile layouts up to 22 qubits, three from 23 — variant 7 forces
-    three wherever legal) against the one-amplitude-per-thread kernels (which are themselves pinned to the oracle
+    three wherever legal, variant 11 two up to 24 qubits; where a layout's runs are shorter than a 128-byte line the tiles that
+    share lines are mapped to one XCD, variant 12 keeps the plain tile order) against the one-amplitude-per-thread kernels (which are themselves pinned to the oracle
     above) — states, expectation values and gradients, complex coefficients."""
     terms = random_terms(n_qubits, 17, 0.002, seed=200 + n_qubits, local=local)
     tsave = torch.linspace(0, 0.03, 7, dtype=torch.float64)
