@@ -187,6 +187,10 @@ typedef struct RydPlanInfo {
     int32_t kernel_family;           /* which forward kernels the problem will run on (reporting only): 0 one-wave lane sweep
                                         (<= 6 qubits), 1 one-workgroup persistent sweep (<= 12 qubits), 2 direct launch per factor,
                                         3 chained LDS-tile launch per factor */
+    char kernel_fwd[80];             /* reporting only: the instantiation the forward factor passes of THIS problem run on, as a profiler
+                                        prints it, e.g. "k_chain<12,10,false,false,true,false>" (tile bits, log2 threads, complex tables,
+                                        adjoint, loop-free, L2-resident) — bench.py names its roofline kernel from here */
+    char kernel_bwd[80];             /* the same for the adjoint factor passes (empty when need_backward was 0) */
 } RydPlanInfo;
 
 #define RYDIFF_PLAN_SCRATCH_BYTES 1024

@@ -66,6 +66,20 @@ def blackman_waveform(duration: int, area) -> Tensor:
     return win * (area / (win.sum() * 1e-3))
 
 
+def kaiser_waveform(duration: int, area, beta: float = 14.0) -> Tensor:
+    """pulser KaiserWaveform: the Kaiser window w[k] = I0(beta sqrt(1 - ((k - a) / a)^2)) / I0(beta), a = (d - 1) / 2, scaled to
+    `area` like the Blackman one; beta = 14 is pulser's default AS RECALLED (no stored output of the reference pins it).  Written
+    from the window's definition (scipy.special.i0), not through numpy.kaiser."""
+    from scipy.special import i0
+
+    d = int(duration)
+    a = (d - 1) / 2.0
+    k = np.arange(d, dtype=np.float64)
+    win = torch.as_tensor(i0(beta * np.sqrt(np.clip(1.0 - ((k - a) / a) ** 2, 0.0, None))) / i0(beta), dtype=RDTYPE)
+    area = _rd(area)
+    return win * (area / (win.sum() * 1e-3))
+
+
 def ramp_waveform(duration: int, start, stop) -> Tensor:
     """pulser RampWaveform: start + (stop-start) * k/(d-1)."""
     start = _rd(start)
@@ -943,9 +957,10 @@ def lindblad_rhs_dense(h: Tensor, rho: Tensor, collapse: list) -> Tensor:
 
 
 def lindblad_continuous_solution(terms: HamTerms, collapse: list, rho0: np.ndarray, tsave: np.ndarray,
-                                 rtol: float = 1e-12, atol: float = 1e-14) -> np.ndarray:
+                                 rtol: float = 1e-12, atol: float = 1e-14, H_t: Callable | None = None) -> np.ndarray:
     """DP5_ME's target: the continuous-time Lindblad solution with the interpolated H(t) (scipy DOP853, tight tolerances).
-    Returns (n_t, dim, dim)."""
+    Returns (n_t, dim, dim).  H_t: a dense H(t) callable instead of the structured ising terms (the other bases, e.g. the literal
+    XY generator of reference_style_dense_H_t; the commutator is taken as written, H rho - rho H, backend.py:495-509)."""
     from scipy.integrate import solve_ivp
 
     dim = 2**terms.n_qubits
@@ -954,7 +969,7 @@ def lindblad_continuous_solution(terms: HamTerms, collapse: list, rho0: np.ndarr
 
     def rhs(t, yv):
         rho = yv.reshape(dim, dim)
-        h = dense_hamiltonian(terms, torch.tensor(t, dtype=torch.float64)).detach().numpy()
+        h = (dense_hamiltonian(terms, torch.tensor(t, dtype=torch.float64)) if H_t is None else H_t(t)).detach().numpy()
         out = -1j * (h @ rho - rho @ h)
         for c, m in zip(cl, cdc):
             out += c @ rho @ c.conj().T - 0.5 * (m @ rho + rho @ m)

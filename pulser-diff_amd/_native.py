@@ -83,6 +83,8 @@ class RydPlanInfo(ctypes.Structure):
         ("workspace_bytes", ctypes.c_size_t),
         ("tape_mode", ctypes.c_int32),
         ("kernel_family", ctypes.c_int32),
+        ("kernel_fwd", ctypes.c_char * 80),
+        ("kernel_bwd", ctypes.c_char * 80),
     ]
 
 

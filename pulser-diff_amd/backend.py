@@ -28,7 +28,8 @@ from torch import Tensor
 
 from . import pulser_adapter, pulses
 from .hamiltonian import COLLAPSE_NOISES, Hamiltonian
-from .lindblad import MAX_ME_QUBITS, ME_DEFAULT_TOL, dissipator_block, doubled_tables, local_collapse_operators, mesolve
+from .lindblad import (MAX_ME_QUBITS, ME_DEFAULT_TOL, dissipator_block, doubled_pair_terms, doubled_tables, local_collapse_operators,
+                       mesolve)
 from .result import SampledResult
 from .simconfig import SimConfig
 from .simresults import CoherentResults, NoisyResults, SimulationResults
@@ -370,22 +371,37 @@ class TorchEmulator:
         dim = 2**n
         master = solver == SolverType.DP5_ME  # collapse operators on top: every realisation is a density matrix
         u_pairs = ham.u_pairs.detach()
+        # the XY exchange lives in dense pair terms (they used to be dropped here, i.e. noisy XY runs evolved without
+        # any interaction).  A badly prepared atom takes no part in it (hamiltonian.py:393-397 skips its pairs), so the pair terms
+        # depend on the realisation: such runs go one configuration per solver call (the configurations are distinct and few).
+        xy_terms = tuple(getattr(ham, "pair_terms", ()))
+        per_run_pairs = bool(xy_terms) and bad_atom_configs is not None and any(any(cfg) for cfg in bad_atom_configs)
+
+        def xy_terms_of(run: int) -> tuple:
+            if not per_run_pairs:
+                return xy_terms
+            bad = bad_atom_configs[run]
+            return tuple(t for t in xy_terms if not (bad[t[0]] or bad[t[1]]))
+
         if master:
             if n > MAX_ME_QUBITS:
                 raise ValueError(f"The master-equation solver keeps 4^N amplitudes; limited to {MAX_ME_QUBITS} qubits.")
             amp, det, u_pairs, amp_masks, det_masks = doubled_tables(amp, det, u_pairs, amp_masks, det_masks, n)
             block = dissipator_block(local_collapse_operators(ham.config, ham.basis_name))
-            spec = ProblemSpec(2 * n, ham.dt, ham.n_samples, amp_masks, det_masks, solver=SolverType.DP5_SE,
-                               tol=tolerance_from_options(options) or ME_DEFAULT_TOL, store_states=True,
-                               pair_terms=tuple((j, n + j, block) for j in range(n)))
+
+            def spec_of(run: int) -> ProblemSpec:
+                return ProblemSpec(2 * n, ham.dt, ham.n_samples, amp_masks, det_masks, solver=SolverType.DP5_SE,
+                                   tol=tolerance_from_options(options) or ME_DEFAULT_TOL, store_states=True,
+                                   pair_terms=doubled_pair_terms(xy_terms_of(run), n, block))
             ket = psi0.to(dev)[:, 0]
             start = torch.outer(ket, ket.conj()).reshape(1, dim * dim)
         else:
-            spec = ProblemSpec(n, ham.dt, ham.n_samples, amp_masks, det_masks, solver=solver,
-                               tol=tolerance_from_options(options), store_states=True)
+            def spec_of(run: int) -> ProblemSpec:
+                return ProblemSpec(n, ham.dt, ham.n_samples, amp_masks, det_masks, solver=solver,
+                                   tol=tolerance_from_options(options), store_states=True, pair_terms=xy_terms_of(run))
             start = psi0.to(dev).T.contiguous()
         # bound the saved states of one batch (n_t x runs x 2^N, or 4^N, amplitudes)
-        chunk = max(1, min(loop_runs, int(self._noisy_state_budget // max(n_t * start.shape[1] * 16, 1))))
+        chunk = 1 if per_run_pairs else max(1, min(loop_runs, int(self._noisy_state_budget // max(n_t * start.shape[1] * 16, 1))))
         eps = meas_errors["epsilon"] if meas_errors else 0.0
         eps_p = meas_errors["epsilon_prime"] if meas_errors else 0.0
         bit_weights = (1 << torch.arange(n, device=dev, dtype=torch.int64))
@@ -394,7 +410,7 @@ class TorchEmulator:
         for r0 in range(0, loop_runs, chunk):
             r1 = min(loop_runs, r0 + chunk)
             with torch.no_grad():
-                states, _ = evolve(amp[r0:r1], det[r0:r1], u_pairs, tsave, start.repeat(r1 - r0, 1), spec, None)
+                states, _ = evolve(amp[r0:r1], det[r0:r1], u_pairs, tsave, start.repeat(r1 - r0, 1), spec_of(r0), None)
                 if master:  # populations = diagonal of rho
                     probs = states.reshape(n_t, r1 - r0, dim, dim).diagonal(dim1=2, dim2=3).real.clamp_min(0.0)
                 else:

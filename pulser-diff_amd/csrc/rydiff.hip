@@ -1954,6 +1954,35 @@ int xcd_group_size(const Runtime& rt, bool adjoint) {
     return 8 * m;
 }
 
+// RydPlanInfo.kernel_fwd / kernel_bwd: the instantiations launch_chain / launch_factor / the one-launch sweeps will pick for this
+// problem (same tests as there), spelled the way rocprofv3 prints them.  Reporting only.
+void describe_kernels(const Runtime& rt, const RydProblem* p, bool backward, RydPlanInfo* info) {
+    const Plan& pl = rt.pl;
+    auto b = [](bool v) { return v ? "true" : "false"; };
+    info->kernel_fwd[0] = info->kernel_bwd[0] = 0;
+    if (info->kernel_family == 3) {
+        const bool fast = pl.ga.n == 1 && pl.gd.n <= 1 && (pl.ga.amp_index_mask[0] & ((1u << pl.NL) - 1u)) == (1u << pl.NL) - 1u;
+        for (int bwd = 0; bwd <= (backward ? 1 : 0); ++bwd) {
+            const bool cplx = (rt.flags & 1) != 0 || (bwd && !p->real_amp_grad);
+            const int lgt = rt.variant == 0 ? ((bwd && cplx) ? 9 : 10) : rt.chain_lgt;
+            const bool res = xcd_group_size(rt, bwd != 0) > 0;
+            std::snprintf(bwd ? info->kernel_bwd : info->kernel_fwd, sizeof(info->kernel_fwd), "k_chain<%d,%d,%s,%s,%s,%s>", kTileBits, lgt,
+                          b(cplx), b(bwd != 0), b(fast), b(res));
+        }
+    } else if (info->kernel_family == 2) {
+        if (direct_global_ok(rt)) {
+            std::snprintf(info->kernel_fwd, sizeof(info->kernel_fwd), "k_factor_direct_global<%d,%s>", pl.N, b(pl.N <= 13));
+            if (backward) std::snprintf(info->kernel_bwd, sizeof(info->kernel_bwd), "k_factor_bwd_direct_global<%d,%s>", pl.N, b(pl.N <= 13));
+        } else {
+            std::snprintf(info->kernel_fwd, sizeof(info->kernel_fwd), "k_factor_direct");
+            if (backward) std::snprintf(info->kernel_bwd, sizeof(info->kernel_bwd), "k_factor_bwd_direct");
+        }
+    } else {
+        std::snprintf(info->kernel_fwd, sizeof(info->kernel_fwd), info->kernel_family == 0 ? "k_lanes_fwd (N=%d)" : "k_persist<%d,...>", pl.N);
+        if (backward) std::snprintf(info->kernel_bwd, sizeof(info->kernel_bwd), info->kernel_family == 0 ? "k_lanes_bwd (N=%d)" : "k_persist_bwd<%d,...>", pl.N);
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -2012,6 +2041,7 @@ int rydiff_plan(const RydProblem* p, int need_tape, int need_backward, void* scr
     rt.prefer_direct = few_tiles(rt, need_backward != 0 || tm != 0);
     if (persist_enabled(rt)) info->kernel_family = lanes_enabled(rt.variant, rt.pl.N, rt.pl.ga.n, rt.pl.gd.n, rt.pl.n_pair) ? 0 : 1;
     else info->kernel_family = chain_enabled(rt) ? 3 : 2;
+    describe_kernels(rt, p, need_backward != 0, info);
     return RYDIFF_OK;
 }
 

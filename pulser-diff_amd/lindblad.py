@@ -93,6 +93,25 @@ def doubled_tables(amp: Tensor, det: Tensor, u_pairs: Tensor, amp_masks, det_mas
     return amp2, det2, u2, am2, dm2
 
 
+MAX_PAIR_TERMS = 28  # RYDIFF_MAX_PAIR_TERMS (include/rydiff.h)
+
+
+def doubled_pair_terms(pair_terms, n: int, dissipator: Optional[np.ndarray] = None) -> tuple:
+    """Dense two-qubit terms of the generator on the doubled register: a Hamiltonian block B on qubits (a, b) — the XY exchange,
+    ``hamiltonian.py:346-366`` — enters the commutator as B on the row qubits (a, b) and -B^T on the column qubits (n + a, n + b)
+    ((1 (x) H^T) vec(rho) = vec(rho H)); the dissipator block sits on every (row qubit j, column qubit j) pair."""
+    out = []
+    if dissipator is not None and np.any(dissipator != 0):
+        out += [(j, n + j, dissipator) for j in range(n)]
+    for a, b, blk in pair_terms:
+        blk = np.asarray(blk, dtype=complex).reshape(4, 4)
+        out += [(a, b, blk), (n + a, n + b, -blk.T)]
+    if len(out) > MAX_PAIR_TERMS:
+        raise NotImplementedError(f"The master equation with pair interactions needs {len(out)} dense two-qubit terms; the library "
+                                  f"takes {MAX_PAIR_TERMS} (XY mode: up to 5 atoms with collapse operators).")
+    return tuple(out)
+
+
 def mesolve(ham, psi0: Tensor, tsave: Tensor, noise: NoiseModel, options: Optional[dict] = None) -> tuple[Tensor, dict]:
     """Density matrices rho(t_k) of shape (n_t, dim, dim, B) for the structured Hamiltonian ``ham`` and the collapse
     operators of ``noise``; psi0: (dim, B) kets (rho0 = |psi0><psi0|, ``backend.py:503``)."""
@@ -103,7 +122,7 @@ def mesolve(ham, psi0: Tensor, tsave: Tensor, noise: NoiseModel, options: Option
     dev = ham.amp_tables.device
     amp2, det2, u2, am2, dm2 = doubled_tables(ham.amp_tables, ham.det_tables, ham.u_pairs, ham.amp_masks, ham.det_masks, n)
     block = dissipator_block(local_collapse_operators(noise, getattr(ham, "basis_name", "ground-rydberg")))
-    pair_terms = tuple((j, n + j, block) for j in range(n)) if np.any(block != 0) else ()
+    pair_terms = doubled_pair_terms(getattr(ham, "pair_terms", ()), n, block)  # dissipators + the XY exchange (if any)
     # default accuracy target one decade below the ket solver's: the calibration of the Magnus step is a little optimistic
     # for non-normal (dissipative) generators
     spec = ProblemSpec(2 * n, ham.dt, ham.n_samples, am2, dm2, solver=SolverType.DP5_SE,

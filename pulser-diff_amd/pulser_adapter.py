@@ -51,9 +51,13 @@ def adapt_samples(obj: Any) -> pulses.SequenceSamples:
     ch_objs = {name: pulses.ChannelInfo(str(ch.addressing), str(ch.basis)) for name, ch in obj._ch_objs.items()}
     mask = getattr(obj, "_slm_mask", None)
     slm = pulses._SlmMask(frozenset(getattr(mask, "targets", ()) or ()), int(getattr(mask, "end", 0) or 0))
-    if getattr(obj, "_magnetic_field", None) is not None or any(ci.basis == "XY" for ci in ch_objs.values()):
-        raise NotImplementedError("XY-mode sequences are not supported by the MI355X-native backend.")
-    return pulses.SequenceSamples(list(obj.channels), samples_list, ch_objs, slm, None, getattr(obj, "_measurement", None))
+    # XY (microwave) samples pass through like the others (the emulator carries the exchange as dense pair terms, up to 8 atoms);
+    # pulser stores the magnetic field of such a sequence as a 3-vector (hamiltonian.py:354-361 reads it)
+    field = getattr(obj, "_magnetic_field", None)
+    if field is None and any(ci.basis == "XY" for ci in ch_objs.values()):
+        field = (0.0, 0.0, 30.0)  # pulser's default field
+    field_t = None if field is None else torch.as_tensor(np.asarray(field, dtype=float), dtype=RD)
+    return pulses.SequenceSamples(list(obj.channels), samples_list, ch_objs, slm, field_t, getattr(obj, "_measurement", None))
 
 
 def adapt_register(reg: Any) -> pulses.Register:
@@ -83,6 +87,8 @@ class _DeviceView(pulses.Device):
         object.__setattr__(self, "_dev", dev)
         object.__setattr__(self, "name", str(getattr(dev, "name", "device")))
         object.__setattr__(self, "interaction_coeff", float(dev.interaction_coeff))
+        if getattr(dev, "interaction_coeff_xy", None) is not None:  # C3 of the microwave (XY) mode, hamiltonian.py:365
+            object.__setattr__(self, "interaction_coeff_xy", float(dev.interaction_coeff_xy))
         object.__setattr__(self, "supported_bases", frozenset(dev.supported_bases))
         object.__setattr__(self, "supports_slm_mask", bool(getattr(dev, "supports_slm_mask", False)))
         object.__setattr__(self, "max_atom_num", getattr(dev, "max_atom_num", None))

@@ -82,6 +82,7 @@ class Channel:
     max_abs_detuning: Optional[float] = None
     max_amp: Optional[float] = None
     max_duration: Optional[int] = None
+    mod_bandwidth: Optional[float] = None  # MHz; recorded so that a request for the MODULATED output is refused, not ignored (sample)
 
     @property
     def basis(self) -> str:
@@ -104,17 +105,38 @@ class Channel:
             raise ValueError("The pulse's duration exceeds the maximum duration allowed for the chosen channel.")
 
 
+# pulser channel options that do not enter the samples this stand-in produces (limits checked by pulser itself, bookkeeping) ...
+_CHANNEL_OPTIONS_WITHOUT_EFFECT = {"clock_period", "min_duration", "min_avg_amp", "max_targets", "propagation_dir"}
+# ... and those that would CHANGE them (delays after a retarget or a phase jump, the EOM mode): only their neutral values are taken
+_CHANNEL_OPTIONS_NEUTRAL = {"min_retarget_interval": (None, 0), "fixed_retarget_t": (None, 0), "phase_jump_time": (None, 0),
+                            "eom_config": (None,)}
+
+
+def _check_channel_options(options: dict) -> None:
+    for key, value in options.items():
+        if key in _CHANNEL_OPTIONS_WITHOUT_EFFECT:
+            continue
+        if key in _CHANNEL_OPTIONS_NEUTRAL:
+            if value not in _CHANNEL_OPTIONS_NEUTRAL[key]:
+                raise NotImplementedError(f"Channel option {key}={value!r} changes the sampled pulses and is not restated by this stand-in; "
+                                          "build the sequence with Pulser itself and hand it over through pulser_adapter.")
+            continue
+        raise TypeError(f"Unknown channel option {key!r}.")
+
+
 class _ChannelKind:
     def __init__(self, kind: str):
         self._kind = kind
 
     def Global(self, max_abs_detuning: Optional[float] = None, max_amp: Optional[float] = None,
-               max_duration: Optional[int] = None, **_ignored) -> Channel:
-        return Channel(self._kind, "Global", max_abs_detuning, max_amp, max_duration)
+               max_duration: Optional[int] = None, mod_bandwidth: Optional[float] = None, **options) -> Channel:
+        _check_channel_options(options)
+        return Channel(self._kind, "Global", max_abs_detuning, max_amp, max_duration, mod_bandwidth)
 
     def Local(self, max_abs_detuning: Optional[float] = None, max_amp: Optional[float] = None,
-              max_duration: Optional[int] = None, **_ignored) -> Channel:
-        return Channel(self._kind, "Local", max_abs_detuning, max_amp, max_duration)
+              max_duration: Optional[int] = None, mod_bandwidth: Optional[float] = None, **options) -> Channel:
+        _check_channel_options(options)
+        return Channel(self._kind, "Local", max_abs_detuning, max_amp, max_duration, mod_bandwidth)
 
 
 Rydberg, Raman, Microwave = _ChannelKind("rydberg"), _ChannelKind("raman"), _ChannelKind("mw")
@@ -154,10 +176,20 @@ class Device:
             raise ValueError(f"All qubit positions must be at most {self.dimensions}D vectors.")
 
 
+# pulser.devices.VirtualDevice fields that only constrain what a sequence may contain (validated by pulser, not read by the emulator)
+_DEVICE_OPTIONS_WITHOUT_EFFECT = {"min_atom_distance", "max_radial_distance", "max_layout_filling", "optimal_layout_filling",
+                                  "min_layout_traps", "max_layout_traps", "max_sequence_duration", "max_runs", "reusable_channels",
+                                  "requires_layout", "accepts_new_layouts", "pre_calibrated_layouts", "dmm_objects",
+                                  "default_noise_model"}
+
+
 def VirtualDevice(name: str, dimensions: int, rydberg_level: int = 70, channel_objects: tuple = (), max_atom_num: Optional[int] = None,
-                  interaction_coeff_xy: float = 3700.0, supports_slm_mask: bool = True, **_ignored) -> Device:
+                  interaction_coeff_xy: float = 3700.0, supports_slm_mask: bool = True, **options) -> Device:
     """pulser.devices.VirtualDevice for the fields this backend reads.  ``rydberg_level`` selects C6 from the table above; a
-    level outside it needs the number from Pulser (it cannot be derived here)."""
+    level outside it needs the number from Pulser (it cannot be derived here).  Unknown options are an error, not ignored."""
+    unknown = set(options) - _DEVICE_OPTIONS_WITHOUT_EFFECT
+    if unknown:
+        raise TypeError(f"Unknown device option(s) {sorted(unknown)}.")
     if rydberg_level not in C6_BY_RYDBERG_LEVEL:
         raise NotImplementedError(f"C6 for Rydberg level {rydberg_level} is not tabulated here (levels: "
                                   f"{sorted(C6_BY_RYDBERG_LEVEL)}); build Device(interaction_coeff=...) with Pulser's value.")
@@ -617,8 +649,18 @@ class Sequence:
 
 def sample(sequence: Sequence, modulation: bool = False, extended_duration: Optional[int] = None) -> SequenceSamples:
     """pulser.sampler.sample restated for the supported subset (backend.py:701-705)."""
-    # modulation=True: pulser modulates the channels that declare a modulation bandwidth; the channels of this stand-in device
-    # (MockDevice) declare none, for which the programmed input IS the output — nothing to do
+    # modulation=True: pulser modulates the channels that declare a modulation bandwidth (Channel.modulate: a Gaussian low-pass of
+    # the programmed input, plus rise / fall times in the schedule).  For channels without one — pulser's MockDevice, the notebooks'
+    # VirtualDevice — the programmed input IS the output.  The filter itself is third-party behaviour no stored output of the
+    # reference pins, so it is NOT restated: asking for the modulated output of a channel that has a bandwidth is refused instead of
+    # silently returning the un-modulated samples (ADVICE r2).  With Pulser installed, pulser_adapter hands over Pulser's own
+    # modulated samples.
+    if modulation:
+        for name in sequence._schedule:
+            bw = getattr(sequence._device_channel.get(name), "mod_bandwidth", None)
+            if bw:
+                raise NotImplementedError(f"Channel {name!r} declares a modulation bandwidth of {bw} MHz: the modulated output is not "
+                                          "restated by this stand-in sampler (use Pulser's sampler through pulser_adapter).")
     channels, samples_list = [], []
     for name, items in sequence._schedule.items():
         amps, dets, phases, slots = [], [], [], []

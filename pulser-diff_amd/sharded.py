@@ -381,7 +381,7 @@ def _native_forward(prob: ShardedProblem, psi_slabs: Tensor, tsave, rank_first: 
         _native.check(L.rydiff_forward(ctypes.byref(p), ctypes.byref(info), ctypes.c_void_p(psi.data_ptr()), ctypes.c_void_p(final.data_ptr()),
                                        ctypes.c_void_p(expect.data_ptr()) if expect is not None else None,
                                        ctypes.c_void_p(workspace.data_ptr()), workspace.numel(), 0, stream))
-    stats = {"degree": info.degree, "total_factors": info.total_factors, "kernel_family": _native.KERNEL_FAMILIES[info.kernel_family],
+    stats = {"degree": info.degree, "total_factors": info.total_factors, "kernel_family": _native.KERNEL_FAMILIES[info.kernel_family], "kernel_fwd": info.kernel_fwd.decode(),
              "spectral": (info.spectral_lo, info.spectral_hi)}
     return final, (expect[0].sum(dim=1) if expect is not None else None), stats
 

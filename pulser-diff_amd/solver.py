@@ -202,7 +202,8 @@ class _RydbergEvolve(torch.autograd.Function):
             raise ValueError(f"Incompatible shape of initial state.Expected {2 ** spec.n_qubits}, got {dim}.")
         _check_shapes(spec, amp_c, det_c, u_c, obs_c, batch)
         n_t = len(ts_host)
-        call = _Call(spec, amp_c, det_c, u_c, ts_host, batch, obs_c)
+        # (real_amp_grad only matters to the adjoint launches; set here as well so that the plan's kernel_bwd names what will run)
+        call = _Call(spec, amp_c, det_c, u_c, ts_host, batch, obs_c, real_amp_grad=not amp.is_complex())
         # the kernel variant this call resolved to (spec field, else the CALLING thread's default): the backward pass runs on the
         # autograd engine's device thread, where that thread-local default is not visible
         ctx.kernel_variant = int(call.problem.kernel_variant)
@@ -255,7 +256,8 @@ class _RydbergEvolve(torch.autograd.Function):
         ctx.stats = {"degree": info.degree, "total_factors": info.total_factors, "rho": info.rho_design,
                      "spectral": (info.spectral_lo, info.spectral_hi), "n_stages": info.n_stages,
                      "tape": ("none", "steps", "full")[min(need_tape, info.tape_mode) if need_tape else 0],
-                     "kernel_family": _native.KERNEL_FAMILIES[info.kernel_family]}
+                     "kernel_family": _native.KERNEL_FAMILIES[info.kernel_family],
+                     "kernel_fwd": info.kernel_fwd.decode(), "kernel_bwd": info.kernel_bwd.decode()}
         spec.options["_last_stats"] = ctx.stats
         return states, expect
 

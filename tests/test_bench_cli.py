@@ -43,3 +43,50 @@ def test_single_rank_default_is_the_headline_workload():
 def test_rank_count_must_match_the_flag():
     r = _run("--gpus", "4", env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "must match" in (r.stderr + r.stdout)
+
+
+def _load_bench():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_under_test", ROOT / "bench.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_state_sharded_leg_failure_only_costs_its_field():
+    """The secondary c5 leg of the default line runs in a child process group.  Without a GPU the child ends
+    with an error: the function must hand back an `error` field (rc and stderr tail) and nothing else."""
+    import argparse
+
+    bench = _load_bench()
+    env_backup = os.environ.pop("RYDIFF_BENCH_STANDIN", None)
+    try:
+        out = bench.c5_leg_in_child_group(argparse.Namespace(variant=0), 1)
+    finally:
+        if env_backup is not None:
+            os.environ["RYDIFF_BENCH_STANDIN"] = env_backup
+    assert set(out) == {"error"} and "rc" in out["error"]
+
+
+def test_state_sharded_leg_is_killed_as_a_group_on_timeout(tmp_path, monkeypatch):
+    """A leg that hangs (here: a stand-in 'interpreter' that starts a grandchild and sleeps) is killed with its whole process
+    group after the time limit; the caller gets an `error` field and carries on — no os._exit from a GPU-initialised rank."""
+    import argparse
+    import time
+
+    bench = _load_bench()
+    pidfile = tmp_path / "grandchild.pid"
+    fake = tmp_path / "hang.sh"
+    fake.write_text(f"#!/bin/bash\nsleep 300 &\necho $! > {pidfile}\nsleep 300\n")
+    fake.chmod(0o755)
+    monkeypatch.setattr(bench.sys, "executable", str(fake))
+    monkeypatch.setattr(bench, "C5_LEG_TIMEOUT_S", 2.0)
+    t0 = time.time()
+    out = bench.c5_leg_in_child_group(argparse.Namespace(variant=0), 2)
+    assert set(out) == {"error"} and "killed" in out["error"]
+    assert time.time() - t0 < 30
+    grandchild = int(pidfile.read_text())
+    time.sleep(0.5)
+    alive = Path(f"/proc/{grandchild}").exists() and "Z" not in Path(f"/proc/{grandchild}/stat").read_text().split()[2]
+    assert not alive

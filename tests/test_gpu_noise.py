@@ -133,3 +133,109 @@ def test_stochastic_noise_in_the_digital_basis(cuda_device):
                                         evaluation_times=times).run(solver=SolverType.KRYLOV_SE)
     p_hot = np.array([hot.results[-1].get(np.binary_repr(i, n), 0.0) for i in range(2**n)])
     assert np.abs(p_hot - p_clean).max() > 0.03
+
+
+def _xy_sequence(hermitian):
+    """Three atoms, a microwave (XY) global channel, a magnetic field: the set-up of tests/test_host_logic.py::_emulator_for_basis."""
+    coords = [[0.0, 0.0], [6.5, 1.0], [2.0, 7.0]]
+    seq = pl.Sequence(pl.Register.from_coordinates(coords), pl.MockDevice)
+    seq.declare_channel("g", "mw_global")
+    seq.set_magnetic_field(0.0, 1.0, 0.3)
+    seq.add(pl.Pulse(pl.BlackmanWaveform(120, 2.1), pl.RampWaveform(120, -4.0, 3.0), 0.4), "g")
+    seq.add(pl.Pulse.ConstantPulse(80, 3.0, 1.5, -0.2), "g")
+    return seq, torch.tensor(coords, dtype=torch.float64)
+
+
+def _xy_oracle_H(sim, coords, drop_atoms=()):
+    """The oracle's literal dense XY generator (hamiltonian.py:346-366, :536) for the emulator's tables; `drop_atoms`: badly prepared
+    atoms — no drive on them and no exchange with them (hamiltonian.py:209-213, :393-397)."""
+    from oracle import restatement as R
+
+    ham = sim._hamiltonian
+    n = ham._size
+    keep = [q for q in range(n) if q not in drop_atoms]
+    amp_terms = [(ham.amp_tables[0][0].cpu(), keep)]
+    det_terms = [(ham.det_tables[0][0].cpu(), keep)]
+    H_all = R.reference_style_dense_H_t(coords, amp_terms, det_terms, ham.dt, ham.n_samples, "XY", magnetic_field=(0.0, 1.0, 0.3))
+    if not drop_atoms:
+        return H_all
+    # exchange terms that involve a dropped atom: remove them = literal generator with those atoms infinitely far away
+    far = coords.clone()
+    for k, q in enumerate(drop_atoms):
+        far[q] = torch.tensor([1e6 * (k + 1), 3e6 * (k + 1)], dtype=torch.float64)
+    return R.reference_style_dense_H_t(far, amp_terms, det_terms, ham.dt, ham.n_samples, "XY", magnetic_field=(0.0, 1.0, 0.3))
+
+
+@pytest.mark.parametrize("hermitian", [False, True])
+def test_xy_exchange_survives_in_the_master_equation_solver(cuda_device, hermitian, monkeypatch):
+    """with solver = DP5_ME the XY exchange — dense pair terms of the library — was not carried onto the doubled
+    register, so the density matrix evolved without interaction.  Now B on the row qubits, -B^T on the column qubits
+    (lindblad.doubled_pair_terms).  Against the oracle's dense Lindblad solution (L = 0, backend.py:497-499) with the literal XY
+    generator, as the reference writes it (one-directional) and with the Hermitian exchange."""
+    from oracle import restatement as R
+    from pulser_diff_amd.hamiltonian import Hamiltonian
+
+    monkeypatch.setattr(Hamiltonian, "XY_HERMITIAN", hermitian)
+    seq, coords = _xy_sequence(hermitian)
+    times = [0.05, 0.12, 0.2]
+    sim = P.TorchEmulator.from_sequence(seq, sampling_rate=0.5, evaluation_times=times)
+    res = sim.run(solver=SolverType.DP5_ME)
+    rho = res.states[..., 0].cpu().numpy()
+    H_lit = _xy_oracle_H(sim, coords)
+    H_t = H_lit
+    if hermitian:  # physical exchange: the literal generator plus the conjugate of its (strictly off-diagonal) interaction part
+        amp0 = [(torch.zeros_like(sim._hamiltonian.amp_tables[0][0].cpu()), [0, 1, 2])]
+        H_int = R.reference_style_dense_H_t(coords, amp0, [], sim._hamiltonian.dt, sim._hamiltonian.n_samples, "XY", magnetic_field=(0.0, 1.0, 0.3))
+        H_t = lambda t: H_lit(t) + H_int(t).mH  # noqa: E731
+    psi0 = sim.initial_state.cpu().numpy().reshape(-1)
+    terms = R.HamTerms(3, torch.zeros(3, dtype=torch.float64), None, None, sim._hamiltonian.dt, sim._hamiltonian.n_samples)
+    ref = R.lindblad_continuous_solution(terms, [], np.outer(psi0, psi0.conj()), sim.evaluation_times.cpu().numpy(), H_t=H_t)
+    assert np.abs(rho - ref).max() < 2e-8
+    # and the interaction matters on this register: without it the populations differ visibly
+    amp_terms = [(sim._hamiltonian.amp_tables[0][0].cpu(), [0, 1, 2])]
+    det_terms = [(sim._hamiltonian.det_tables[0][0].cpu(), [0, 1, 2])]
+    far = coords * 1e4
+    H_free = R.reference_style_dense_H_t(far, amp_terms, det_terms, sim._hamiltonian.dt, sim._hamiltonian.n_samples, "XY", magnetic_field=(0.0, 1.0, 0.3))
+    free = R.lindblad_continuous_solution(terms, [], np.outer(psi0, psi0.conj()), sim.evaluation_times.cpu().numpy(), H_t=H_free)
+    assert np.abs(free - ref).max() > 1e-2
+
+
+def test_xy_noisy_runs_keep_the_exchange_and_leave_badly_prepared_atoms_out(cuda_device):
+    """XY + SPAM with eta > 0 went through _run_noisy WITHOUT the pair terms.  Now every bad-atom configuration is
+    one solver call whose pair terms skip the badly prepared atoms (hamiltonian.py:393-397).  Two fixed configurations, many
+    shots: the sampled distribution at the final time against the oracle's mixture of the two literal evolutions."""
+    from oracle import restatement as R
+
+    seq, coords = _xy_sequence(False)
+    cfg = P.SimConfig(noise="SPAM", eta=0.3, epsilon=0.0, epsilon_prime=0.0, runs=2, samples_per_run=20000)
+    times = [0.1, 0.2]
+    sim = P.TorchEmulator.from_sequence(seq, sampling_rate=0.5, config=cfg, evaluation_times=times)
+    psi0 = sim.initial_state
+    if psi0.ndim == 1:
+        psi0 = psi0.unsqueeze(1)
+    torch.manual_seed(5)
+    configs, reps = [(False, False, False), (False, True, False)], [1, 1]
+    res = sim._run_noisy(psi0, SolverType.KRYLOV_SE, {}, reps, configs, {"epsilon": 0.0, "epsilon_prime": 0.0})
+    assert isinstance(res, NoisyResults)
+    p_ref = np.zeros(8)
+    for bad in configs:
+        drop = tuple(q for q in range(3) if bad[q])
+        st = R.krylov_map_from_dense_H(_xy_oracle_H(sim, coords, drop), psi0.cpu(), sim.evaluation_times.detach().cpu())
+        p = (st[-1, :, 0].abs() ** 2).numpy()
+        p_ref += 0.5 * p / p.sum()  # (the literal generator does not conserve the norm; multinomial sampling normalises)
+    # XY bitstrings: '1' = d = index bit 1 (the index itself), qubit 0 = most significant bit
+    p_got = np.array([res.results[-1].get(np.binary_repr(i, 3), 0.0) for i in range(8)])
+    assert abs(p_got.sum() - 1.0) < 1e-12
+    assert np.abs(p_got - p_ref).max() < 5 * 0.5 / np.sqrt(40000)
+    # the exchange is visible at this accuracy: the same mixture WITHOUT any interaction is off by more than the bar
+    p_free = np.zeros(8)
+    for bad in configs:
+        drop = tuple(q for q in range(3) if bad[q])
+        ham = sim._hamiltonian
+        keep = [q for q in range(3) if q not in drop]
+        H_free = R.reference_style_dense_H_t(coords * 1e4, [(ham.amp_tables[0][0].cpu(), keep)], [(ham.det_tables[0][0].cpu(), keep)], ham.dt,
+                                             ham.n_samples, "XY", magnetic_field=(0.0, 1.0, 0.3))
+        st = R.krylov_map_from_dense_H(H_free, psi0.cpu(), sim.evaluation_times.detach().cpu())
+        p = (st[-1, :, 0].abs() ** 2).numpy()
+        p_free += 0.5 * p / p.sum()
+    assert np.abs(p_free - p_ref).max() > 4 * 5 * 0.5 / np.sqrt(40000)

@@ -26,23 +26,23 @@ def _sim(amp_wf, det_wf, cfg, n_rows=2):
     return sim
 
 
-def _oracle_terms(sim):
-    ham = sim._hamiltonian
-    n = ham._size
-    if ham.amp_masks == ((1 << n) - 1,) and len(ham._det_terms) <= 1:  # one global term
-        det = ham._det_terms[0][0] if ham._det_terms else torch.zeros_like(ham._amp_terms[0][0].real)
-        return R.HamTerms(n, ham._u_pairs_host, ham._amp_terms[0][0], det, ham.dt, ham.n_samples, list(range(n)), list(range(n)))
-    terms = R.HamTerms(n, ham._u_pairs_host, None, None, ham.dt, ham.n_samples)
-    qubits = lambda m: [q for q in range(n) if m >> q & 1]
-    terms.extra_amp = [(c, qubits(m)) for c, m in ham._amp_terms]
-    terms.extra_det = [(c, qubits(m)) for c, m in ham._det_terms]
-    return terms
+def _oracle_terms(sim, wf, amp_fraction=1.0):
+    """The oracle's Hamiltonian terms from the waveform DEFINITIONS (oracle waveform restatements -> concat_pulses -> build_terms)
+    and the register's coordinates — nothing is read from the product's coefficient tables, so these tests pin
+    the samplers (Blackman, Kaiser, constant) and the table construction as well as the solver."""
+    coords = torch.stack([sim._register.qubits[q] for q in sim._register.qubit_ids])
+    seq = R.concat_pulses([(wf[2]() * amp_fraction, wf[3](), 0.0)])
+    return R.build_terms(seq, coords, 1.0)
 
 
+# (product amplitude waveform, product detuning waveform, oracle amplitude samples, oracle detuning samples)
 WAVEFORMS = [
-    (lambda: pl.ConstantWaveform(800, 5.0), lambda: pl.ConstantWaveform(800, 0.0)),
-    (lambda: pl.BlackmanWaveform(800, 2 * torch.pi), lambda: pl.ConstantWaveform(800, 2.5)),
-    (lambda: pl.KaiserWaveform(800, 2 * torch.pi), lambda: pl.ConstantWaveform(800, 5.0)),
+    (lambda: pl.ConstantWaveform(800, 5.0), lambda: pl.ConstantWaveform(800, 0.0),
+     lambda: R.constant_waveform(800, 5.0), lambda: R.constant_waveform(800, 0.0)),
+    (lambda: pl.BlackmanWaveform(800, 2 * torch.pi), lambda: pl.ConstantWaveform(800, 2.5),
+     lambda: R.blackman_waveform(800, 2 * torch.pi), lambda: R.constant_waveform(800, 2.5)),
+    (lambda: pl.KaiserWaveform(800, 2 * torch.pi), lambda: pl.ConstantWaveform(800, 5.0),
+     lambda: R.kaiser_waveform(800, 2 * torch.pi), lambda: R.constant_waveform(800, 5.0)),
 ]
 
 
@@ -57,7 +57,7 @@ def test_lindblad_noise(cuda_device, wf, noise):
     res = sim.run(solver=SolverType.DP5_ME)
     psi0 = R.all_ground_state(2)[:, 0]
     oracle_noise = {k: (v if k != "eff_noise" else [(r, o.numpy()) for r, o in v]) for k, v in noise.items()}
-    ref = R.lindblad_continuous_solution(_oracle_terms(sim), R.collapse_operators(2, oracle_noise),
+    ref = R.lindblad_continuous_solution(_oracle_terms(sim, wf), R.collapse_operators(2, oracle_noise),
                                          torch.outer(psi0, psi0.conj()).numpy(), sim.evaluation_times.numpy())
     for idx in range(len(res)):
         assert np.abs(res.states[idx].squeeze(-1).cpu().numpy() - ref[idx]).max() < 1e-8
@@ -69,9 +69,9 @@ def test_laser_waist(cuda_device, wf):
     sim = _sim(wf[0](), wf[1](), P.SimConfig(noise="amplitude", amp_sigma=0.0, laser_waist=100.0))
     res = sim.run(solver=SolverType.DP5_SE)
     assert isinstance(res, P.simresults.CoherentResults) and sim._hamiltonian.amp_masks == (1, 2)
-    ref = R.continuous_solution(_oracle_terms(sim), R.all_ground_state(2).numpy(), sim.evaluation_times.numpy())
+    frac = np.exp(-((4.0 / 100.0) ** 2))  # both atoms sit 4 um from the beam axis (hamiltonian.py:196-201)
+    ref = R.continuous_solution(_oracle_terms(sim, wf, amp_fraction=frac), R.all_ground_state(2).numpy(), sim.evaluation_times.numpy())
     assert np.abs(res.states.cpu().numpy() - ref).max() < 1e-8
-    frac = np.exp(-((4.0 / 100.0) ** 2))  # both atoms sit 4 um from the beam axis
     assert abs((sim._hamiltonian.amp_tables[0, 0, 400] / (0.5 * wf[0]().samples[400])).real.item() - frac) < 1e-12
 
 
@@ -110,8 +110,8 @@ def test_single_qubit(cuda_device):
     seq.add(pl.Pulse.ConstantPulse(100, 2.0, 1.0, 0.0), "rydberg_global")
     sim = P.TorchEmulator.from_sequence(seq)
     res = sim.run()
-    ham = sim._hamiltonian
-    terms = R.HamTerms(1, ham._u_pairs_host, ham._amp_terms[0][0], ham._det_terms[0][0], ham.dt, ham.n_samples, [0], [0])
+    terms = R.build_terms(R.concat_pulses([(R.constant_waveform(100, 2.0), R.constant_waveform(100, 1.0), 0.0)]),
+                          torch.zeros(1, 2, dtype=torch.float64), 1.0)  # from the pulse's definition, not from the product's tables
     ref = R.continuous_solution(terms, R.all_ground_state(1).numpy(), sim.evaluation_times.numpy())
     assert np.abs(res.states.cpu().numpy() - ref).max() < 1e-8
     z = res.expect([total_magnetization(1)])[0].real

@@ -99,17 +99,23 @@ def test_native_sharded_run_matches_single_gpu_solver(cuda_device, n_qubits, g, 
     assert np.abs(e_sh.cpu().numpy() - expect[0, :, 0].cpu().numpy()).max() < 1e-10
 
 
-def _two_rank_worker(rank, world, port, n_qubits, g, seed, out_q):
+def _two_rank_worker(rank, world, port, n_qubits, g, seed, out_q, backend="gloo"):
+    import datetime
     import os
 
     import torch.distributed as dist
 
     from pulser_diff_amd.sharded import run_distributed_native
 
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if backend == "nccl":  # RCCL: one GPU per rank, slabs over xGMI (posted from the library's exchange callback)
+        dev = torch.device("cuda", rank)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=120))
+    else:
         dev = torch.device("cuda", 0)  # every rank on the box's one GPU; gloo carries the slabs
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
         terms, prob = _problem(n_qubits, g, seed=seed)
         tsave = np.linspace(0, 0.02, 6)
         gen = torch.Generator().manual_seed(n_qubits)
@@ -158,3 +164,46 @@ def test_native_sharded_run_over_processes(cuda_device, n_qubits, g):
     for r in results:  # every rank holds the all-reduced expectation values
         assert np.abs(r[2] - expect[0, :, 0].cpu().numpy()).max() < 1e-10
         assert r[3] == ("chained-tiles" if n_qubits - g > 12 else "direct")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL path needs one GPU per rank (runs on the driver's multi-GPU box)")
+@pytest.mark.parametrize("n_qubits,g", [(15, 1), (16, 2)])
+def test_native_sharded_run_over_rccl(cuda_device, n_qubits, g):
+    """run_distributed_native with the NCCL (= RCCL) backend, one GPU per rank: the branch that posts the hypercube
+    batch_isend_irecv from the library's exchange callback and orders the wait on the launch stream (sharded.py).  It has no
+    one-GPU stand-in — this pool's boxes have one GPU — so the test is skipped here and runs wherever >= 2 GPUs are visible
+    (VERDICT r2 item 5b).  Bounded: a stuck transport fails the ranks after 120 s and the test after 240 s."""
+    import socket
+
+    import torch.multiprocessing as mp
+    from pulser_diff_amd.solver import SolverType, evolve
+
+    world = 2**g
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"{world} GPUs needed")
+    with socket.socket() as sck:
+        sck.bind(("127.0.0.1", 0))
+        port = sck.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, n_qubits, g, 900 + n_qubits, q, "nccl")) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    try:
+        results = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    finally:
+        for p_ in procs:
+            p_.join(timeout=30)
+            if p_.is_alive():
+                p_.kill()
+    assert all(p_.exitcode == 0 for p_ in procs)
+    terms, prob = _problem(n_qubits, g, seed=900 + n_qubits)
+    gen = torch.Generator().manual_seed(n_qubits)
+    psi0 = torch.randn(2**n_qubits, generator=gen, dtype=torch.complex128)
+    psi0 = (psi0 / psi0.norm()).to(cuda_device)
+    zd = R.total_magnetization_diag(n_qubits).to(cuda_device)
+    amp, det, u, spec = to_native(terms, cuda_device, SolverType.KRYLOV_SE)
+    states, expect = evolve(amp, det, u, torch.linspace(0, 0.02, 6, dtype=torch.float64), psi0[None], spec, zd[None])
+    assert rel_err(np.concatenate([r[1] for r in results]), states[-1, 0].cpu().numpy()) < 1e-11
+    for r in results:
+        assert np.abs(r[2] - expect[0, :, 0].cpu().numpy()).max() < 1e-10
