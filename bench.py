@@ -679,8 +679,10 @@ def cpu_model() -> str:
 
 
 def cpu_baseline(workload, n_qubits, coords, T, seg_len, omega, delta, fixed_tables, u_pairs, tsave, n_steps, device):
-    """The reference's CPU pattern (sparse-COO H(t) re-assembly + Krylov exponential per time step, torch CPU fp64, all host
-    threads), restated in oracle/ ("port"), timed on `n_steps` CONSECUTIVE steps taken from the MIDDLE of the trajectory: the
+    """The reference's CPU pattern (sparse-COO H(t) re-assembly + Krylov exponential per time step, torch CPU fp64), restated in
+    oracle/ ("port"), at the BEST of a few thread counts (torch's sparse-COO ops barely scale and lose when oversubscribed: a short
+    probe — one H(t) re-assembly + two sparse mat-vecs — picks among 1 / 8 / 32 / 64 / all host threads), timed
+    on `n_steps` CONSECUTIVE steps taken from the MIDDLE of the trajectory: the
     state there is spread over the whole basis (typical Krylov dimension), whereas the first steps start from one basis state.
     The mid-trajectory state itself comes from the GPU run (it only seeds the timing sample).  Forward only: at 20 qubits
     torch autograd through a sparse H cannot run at all (it materialises a dense 2^N x 2^N gradient)."""
@@ -714,13 +716,25 @@ def cpu_baseline(workload, n_qubits, coords, T, seg_len, omega, delta, fixed_tab
         terms = R.build_terms(seq, coords, 1.0)
         H_t = R.reference_style_H_t_fast(terms)
         ts = R.evaluation_times(seq.tot_duration, 1.0)[k0: k0 + n_steps + 1]
+        probe = {}
+        for c in sorted({c for c in (1, 8, 32, 64, cores) if c <= cores}):
+            torch.set_num_threads(c)
+            t0 = time.perf_counter()
+            h = H_t(float(ts[1]))
+            w = torch.sparse.mm(h, psi_mid[:, None])
+            w = torch.sparse.mm(h, w)
+            probe[c] = time.perf_counter() - t0
+            del h, w
+        best = min(probe, key=probe.get)
+        torch.set_num_threads(best)
         t0 = time.perf_counter()
         R.reference_pattern_krylov(terms, psi_mid, ts, H_t)
         dt = time.perf_counter() - t0
-        res = {"value": n_steps / dt, "unit": "time-steps/s", "cores": torch.get_num_threads(), "cpu": cpu_model(), "kind": "port",
+        res = {"value": n_steps / dt, "unit": "time-steps/s", "cores": torch.get_num_threads(), "host_threads": cores,
+               "threads_probed_s": {str(c): round(v, 3) for c, v in probe.items()}, "cpu": cpu_model(), "kind": "port",
                "sample": f"time steps {k0}..{k0 + n_steps} (middle of the trajectory, state spread over the basis) of the {T} steps of "
                          f"the same {n_qubits}-qubit workload, forward only: sparse-COO H(t) rebuild + Krylov exp per step "
-                         f"(oracle/restatement.py); {dt:.1f} s"}
+                         f"(oracle/restatement.py) on the best of the probed thread counts ({best}); {dt:.1f} s"}
         if n_qubits <= 16:
             # second, fairer CPU line: the oracle's own MATRIX-FREE Krylov map (numpy, one core), no sparse H
             # (dropped at 20 qubits, where one step takes over a minute)

@@ -232,7 +232,26 @@ class _RydbergEvolve(torch.autograd.Function):
                 # (rydiff_plan holds the library's only stream synchronisation)
                 _native.check(L.rydiff_plan(ctypes.byref(call.problem), need_tape, int(needs_grad), _ptr(scratch),
                                             stream, ctypes.byref(info)))
-            workspace = torch.empty(info.workspace_bytes, dtype=torch.uint8, device=dev)
+            workspace = None
+            for attempt in range(3):
+                try:
+                    workspace = torch.empty(info.workspace_bytes, dtype=torch.uint8, device=dev)
+                    break
+                except torch.OutOfMemoryError:
+                    # The fit test above counts the caching allocator's free blocks as reusable, but a cached block that is a little
+                    # SMALLER than this request (the previous run's tape) cannot serve it.  First hand the cache back to the driver
+                    # and ask again; if the full tape still does not come (memory the driver has not returned yet, a second tenant),
+                    # fall back to one state per save point + recompute, which is what the solver does whenever the full tape
+                    # does not fit.  An explicitly requested full tape is not downgraded.
+                    if attempt == 0:
+                        torch.cuda.synchronize(dev)
+                        torch.cuda.empty_cache()
+                    elif attempt == 1 and need_tape == 2 and spec.tape != "full":
+                        need_tape = int(bool(needs_grad and not spec.store_states))
+                        _native.check(L.rydiff_plan(ctypes.byref(call.problem), need_tape, int(needs_grad), _ptr(scratch),
+                                                    stream, ctypes.byref(info)))
+                    else:
+                        raise
             states = (torch.empty((n_t, batch, dim), dtype=torch.complex128, device=dev) if spec.store_states
                       else torch.empty((0, batch, dim), dtype=torch.complex128, device=dev))
             n_obs = call.problem.n_obs

@@ -146,24 +146,31 @@ def _xy_sequence(hermitian):
     return seq, torch.tensor(coords, dtype=torch.float64)
 
 
-def _xy_oracle_H(sim, coords, drop_atoms=()):
-    """The oracle's literal dense XY generator (hamiltonian.py:346-366, :536) for the emulator's tables; `drop_atoms`: badly prepared
-    atoms — no drive on them and no exchange with them (hamiltonian.py:209-213, :393-397)."""
+def _xy_tables(seq):
+    """0.5 amp exp(-i phase) and -0.5 det of the global microwave channel from the sequence's RAW per-ns samples (+ the one trailing
+    sample of backend.py:113-115), sub-sampled like hamiltonian.py:83-91 — independent of the emulator's own tables."""
     from oracle import restatement as R
 
-    ham = sim._hamiltonian
-    n = ham._size
-    keep = [q for q in range(n) if q not in drop_atoms]
-    amp_terms = [(ham.amp_tables[0][0].cpu(), keep)]
-    det_terms = [(ham.det_tables[0][0].cpu(), keep)]
-    H_all = R.reference_style_dense_H_t(coords, amp_terms, det_terms, ham.dt, ham.n_samples, "XY", magnetic_field=(0.0, 1.0, 0.3))
-    if not drop_atoms:
-        return H_all
-    # exchange terms that involve a dropped atom: remove them = literal generator with those atoms infinitely far away
-    far = coords.clone()
+    raw = pl.sample(seq).samples_list[0]
+    zero = torch.zeros(1, dtype=torch.float64)
+    n_full = raw.amp.numel() + 1
+    c = 0.5 * torch.cat([raw.amp, zero]) * torch.exp(-1j * torch.cat([raw.phase, raw.phase[-1:]]).to(torch.complex128))
+    d = -0.5 * torch.cat([raw.det, zero])
+    return R.adapt_to_sampling_rate(c, 0.5, n_full), R.adapt_to_sampling_rate(d, 0.5, n_full), 0.002, int(0.5 * n_full)
+
+
+def _xy_oracle_H(seq, coords, drop_atoms=(), interaction=True):
+    """The oracle's literal dense XY generator (hamiltonian.py:346-366, :536).  `drop_atoms`: badly prepared atoms — no drive on them
+    and no exchange with them (hamiltonian.py:209-213, :393-397), stated as the literal generator with those atoms far away;
+    interaction=False: all atoms far apart."""
+    from oracle import restatement as R
+
+    c, d, dt, n_s = _xy_tables(seq)
+    keep = [q for q in range(coords.shape[0]) if q not in drop_atoms]
+    far = coords.clone() if interaction else coords * 1e4
     for k, q in enumerate(drop_atoms):
         far[q] = torch.tensor([1e6 * (k + 1), 3e6 * (k + 1)], dtype=torch.float64)
-    return R.reference_style_dense_H_t(far, amp_terms, det_terms, ham.dt, ham.n_samples, "XY", magnetic_field=(0.0, 1.0, 0.3))
+    return R.reference_style_dense_H_t(far, [(c, keep)], [(d, keep)], dt, n_s, "XY", magnetic_field=(0.0, 1.0, 0.3))
 
 
 @pytest.mark.parametrize("hermitian", [False, True])
@@ -181,22 +188,19 @@ def test_xy_exchange_survives_in_the_master_equation_solver(cuda_device, hermiti
     sim = P.TorchEmulator.from_sequence(seq, sampling_rate=0.5, evaluation_times=times)
     res = sim.run(solver=SolverType.DP5_ME)
     rho = res.states[..., 0].cpu().numpy()
-    H_lit = _xy_oracle_H(sim, coords)
+    H_lit = _xy_oracle_H(seq, coords)
     H_t = H_lit
     if hermitian:  # physical exchange: the literal generator plus the conjugate of its (strictly off-diagonal) interaction part
-        amp0 = [(torch.zeros_like(sim._hamiltonian.amp_tables[0][0].cpu()), [0, 1, 2])]
-        H_int = R.reference_style_dense_H_t(coords, amp0, [], sim._hamiltonian.dt, sim._hamiltonian.n_samples, "XY", magnetic_field=(0.0, 1.0, 0.3))
+        c, _d, dt, n_s = _xy_tables(seq)
+        H_int = R.reference_style_dense_H_t(coords, [(torch.zeros_like(c), [0, 1, 2])], [], dt, n_s, "XY", magnetic_field=(0.0, 1.0, 0.3))
         H_t = lambda t: H_lit(t) + H_int(t).mH  # noqa: E731
     psi0 = sim.initial_state.cpu().numpy().reshape(-1)
     terms = R.HamTerms(3, torch.zeros(3, dtype=torch.float64), None, None, sim._hamiltonian.dt, sim._hamiltonian.n_samples)
     ref = R.lindblad_continuous_solution(terms, [], np.outer(psi0, psi0.conj()), sim.evaluation_times.cpu().numpy(), H_t=H_t)
     assert np.abs(rho - ref).max() < 2e-8
     # and the interaction matters on this register: without it the populations differ visibly
-    amp_terms = [(sim._hamiltonian.amp_tables[0][0].cpu(), [0, 1, 2])]
-    det_terms = [(sim._hamiltonian.det_tables[0][0].cpu(), [0, 1, 2])]
-    far = coords * 1e4
-    H_free = R.reference_style_dense_H_t(far, amp_terms, det_terms, sim._hamiltonian.dt, sim._hamiltonian.n_samples, "XY", magnetic_field=(0.0, 1.0, 0.3))
-    free = R.lindblad_continuous_solution(terms, [], np.outer(psi0, psi0.conj()), sim.evaluation_times.cpu().numpy(), H_t=H_free)
+    free = R.lindblad_continuous_solution(terms, [], np.outer(psi0, psi0.conj()), sim.evaluation_times.cpu().numpy(),
+                                          H_t=_xy_oracle_H(seq, coords, interaction=False))
     assert np.abs(free - ref).max() > 1e-2
 
 
@@ -220,7 +224,7 @@ def test_xy_noisy_runs_keep_the_exchange_and_leave_badly_prepared_atoms_out(cuda
     p_ref = np.zeros(8)
     for bad in configs:
         drop = tuple(q for q in range(3) if bad[q])
-        st = R.krylov_map_from_dense_H(_xy_oracle_H(sim, coords, drop), psi0.cpu(), sim.evaluation_times.detach().cpu())
+        st = R.krylov_map_from_dense_H(_xy_oracle_H(seq, coords, drop), psi0.cpu(), sim.evaluation_times.detach().cpu())
         p = (st[-1, :, 0].abs() ** 2).numpy()
         p_ref += 0.5 * p / p.sum()  # (the literal generator does not conserve the norm; multinomial sampling normalises)
     # XY bitstrings: '1' = d = index bit 1 (the index itself), qubit 0 = most significant bit
@@ -231,11 +235,7 @@ def test_xy_noisy_runs_keep_the_exchange_and_leave_badly_prepared_atoms_out(cuda
     p_free = np.zeros(8)
     for bad in configs:
         drop = tuple(q for q in range(3) if bad[q])
-        ham = sim._hamiltonian
-        keep = [q for q in range(3) if q not in drop]
-        H_free = R.reference_style_dense_H_t(coords * 1e4, [(ham.amp_tables[0][0].cpu(), keep)], [(ham.det_tables[0][0].cpu(), keep)], ham.dt,
-                                             ham.n_samples, "XY", magnetic_field=(0.0, 1.0, 0.3))
-        st = R.krylov_map_from_dense_H(H_free, psi0.cpu(), sim.evaluation_times.detach().cpu())
+        st = R.krylov_map_from_dense_H(_xy_oracle_H(seq, coords, drop, interaction=False), psi0.cpu(), sim.evaluation_times.detach().cpu())
         p = (st[-1, :, 0].abs() ** 2).numpy()
         p_free += 0.5 * p / p.sum()
     assert np.abs(p_free - p_ref).max() > 4 * 5 * 0.5 / np.sqrt(40000)
