@@ -23,7 +23,7 @@ for n in [int(q) for q in os.environ.get('QUBITS', '2,4,6,8,10,12').split(',')]:
     x = torch.arange(2**n, device=dev)
     z = sum(1.0 - 2.0 * ((x >> j) & 1).to(torch.float64) for j in range(n))
     mask = (1 << n) - 1
-    spec = ProblemSpec(n, 0.002, T + 1, (mask,), (mask,), solver=SolverType.KRYLOV_SE, store_states=os.environ.get('STORE', '1') == '1')
+    spec = ProblemSpec(n, 0.002, T + 1, (mask,), (mask,), solver=SolverType.KRYLOV_SE, store_states=os.environ.get('STORE', '1') == '1', tape=os.environ.get('TAPE', 'auto'))
 
     def fwd(grad):
         st, ex = evolve(amp if grad else amp.detach(), det if grad else det.detach(), u, ts, psi0, spec, z[None])
