@@ -37,6 +37,12 @@ from .solver import ProblemSpec, SolverType, evolve, sesolve, tolerance_from_opt
 from .utils import DiagonalObservable
 
 
+def _same_field(a, b) -> bool:
+    if a is None or b is None:
+        return a is None and b is None
+    return bool(torch.equal(torch.as_tensor(a, dtype=torch.float64), torch.as_tensor(b, dtype=torch.float64)))
+
+
 class TorchEmulator:
     r"""Emulator of a pulse sequence using the MI355X-native solver.
 
@@ -48,52 +54,49 @@ class TorchEmulator:
         config: Configuration to be used for this simulation.
         evaluation_times: "Full", "Minimal", an array of times in us, or a float fraction (``backend.py:47-58``).
         compute_device: torch device of the native solver (extension; default "cuda").
+        xy_hermitian: XY mode only (extension): True = the physical exchange U (s+s- + s-s+); None / False = the exchange as the
+            reference assembles it (one-directional, non-Hermitian generator; a warning is issued once).
     """
 
     def __init__(self, sampled_seq, register, device, sampling_rate: float = 1.0, config: Optional[SimConfig] = None,
-                 evaluation_times: Union[float, str, Any] = "Full", compute_device: Union[str, torch.device] = "cuda") -> None:
+                 evaluation_times: Union[float, str, Any] = "Full", compute_device: Union[str, torch.device] = "cuda",
+                 xy_hermitian: Optional[bool] = None) -> None:
         # real Pulser objects are converted by attribute access (pulser_adapter.py); anything else is a TypeError
         sampled_seq = pulser_adapter.adapt_samples(sampled_seq)
         register = pulser_adapter.adapt_register(register)
         device = pulser_adapter.adapt_device(device)
+        ids = set(register.qubit_ids)
+        local_targets = {ch: set().union(*(slot.targets for slot in cs.slots))
+                         for ch, cs in sampled_seq.channel_samples.items() if sampled_seq._ch_objs[ch].addressing == "Local"}
+        # what must hold between samples, register and device (backend.py:72-101), each with the reference's message
         if sampled_seq.max_duration == 0:
             raise ValueError("SequenceSamples is empty.")
         device.validate_register(register)
+        for broken, message in (
+            (sampled_seq._slm_mask.end > 0 and not device.supports_slm_mask, "Samples use SLM mask but device does not have one."),
+            (not sampled_seq.used_bases <= set(device.supported_bases), "Bases used in samples should be supported by device."),
+            (not sampled_seq._slm_mask.targets <= ids, "The ids of qubits targeted in SLM mask should be defined in register."),
+            (any(not t <= ids for t in local_targets.values()), "The ids of qubits targeted in Local channels should be defined in register."),
+            (not (0 < sampling_rate <= 1.0), f"The sampling rate (`sampling_rate` = {sampling_rate}) must be greater than 0 and "
+                                              "less than or equal to 1."),
+            (int(sampled_seq.max_duration * sampling_rate) < 4, "`sampling_rate` is too small, less than 4 data points."),
+        ):
+            if broken:
+                raise ValueError(message)
         self._register = register
-        if sampled_seq._slm_mask.end > 0 and not device.supports_slm_mask:
-            raise ValueError("Samples use SLM mask but device does not have one.")
-        if not sampled_seq.used_bases <= set(device.supported_bases):
-            raise ValueError("Bases used in samples should be supported by device.")
-        if not sampled_seq._slm_mask.targets <= set(register.qubit_ids):
-            raise ValueError("The ids of qubits targeted in SLM mask should be defined in register.")
-        samples_list = []
-        for ch, ch_samples in sampled_seq.channel_samples.items():
-            if sampled_seq._ch_objs[ch].addressing == "Local":
-                if not set().union(*(slot.targets for slot in ch_samples.slots)) <= set(register.qubit_ids):
-                    raise ValueError("The ids of qubits targeted in Local channels" " should be defined in register.")
-                samples_list.append(ch_samples)
-            else:
-                # Replace targets of Global channels by qubits of register (backend.py:102-112)
-                samples_list.append(replace(ch_samples, slots=[replace(slot, targets=frozenset(register.qubit_ids))
-                                                               for slot in ch_samples.slots]))
-        _sampled_seq = replace(sampled_seq, samples_list=samples_list)
-        self._tot_duration = _sampled_seq.max_duration
-        self.samples_obj = _sampled_seq.extend_duration(self._tot_duration + 1)  # backend.py:115
-
-        if not (0 < sampling_rate <= 1.0):
-            raise ValueError(
-                "The sampling rate (`sampling_rate` = "
-                f"{sampling_rate}) must be greater than 0 and "
-                "less than or equal to 1."
-            )
-        if int(self._tot_duration * sampling_rate) < 4:
-            raise ValueError("`sampling_rate` is too small, less than 4 data points.")
+        # a global channel drives the atoms of THIS register, whatever targets its slots were sampled with (backend.py:102-112);
+        # the Hamiltonian reads one sample beyond the last instruction (backend.py:113-115)
+        everyone = frozenset(register.qubit_ids)
+        samples_list = [cs if ch in local_targets else replace(cs, slots=[replace(slot, targets=everyone) for slot in cs.slots])
+                        for ch, cs in sampled_seq.channel_samples.items()]
+        self._tot_duration = sampled_seq.max_duration
+        self.samples_obj = replace(sampled_seq, samples_list=samples_list).extend_duration(self._tot_duration + 1)
         self._compute_device = torch.device(compute_device)
         self._noisy_state_budget = 8 * 2**30  # bytes of saved states per batch of noise realisations
         noise_model = config.to_noise_model() if config else SimConfig().to_noise_model()
         self._config = config if config else SimConfig()
         self._hamiltonian = Hamiltonian(self.samples_obj, self._register.qubits, device, sampling_rate, noise_model,
-                                        compute_device=self._compute_device)
+                                        compute_device=self._compute_device, xy_hermitian=xy_hermitian)
         self._eval_times_array: Tensor
         self.set_evaluation_times(evaluation_times)
         # backend.py:141-147: the sequence's measurement basis, else the Hamiltonian's ("digital" for the three-level basis)
@@ -126,32 +129,25 @@ class TorchEmulator:
     def config(self) -> SimConfig:
         return self._config
 
-    def set_config(self, cfg: SimConfig) -> None:
-        """backend.py:183-198."""
+    def _require_simconfig(self, cfg, what: str, sep: str) -> None:
+        """A SimConfig whose noise types the interaction mode knows (backend.py:185-196, :202-213)."""
         if not isinstance(cfg, SimConfig):
-            raise ValueError(f"Object {cfg} is not a valid `SimConfig`.")
-        not_supported = set(cfg.noise) - cfg.supported_noises[self._hamiltonian._interaction]
-        if not_supported:
-            raise NotImplementedError(
-                f"Interaction mode '{self._hamiltonian._interaction}' does not"
-                " support simulation of noise types:"
-                f"{', '.join(not_supported)}."
-            )
+            raise ValueError(what)
+        mode = self._hamiltonian._interaction
+        foreign = set(cfg.noise) - cfg.supported_noises[mode]
+        if foreign:
+            raise NotImplementedError(f"Interaction mode '{mode}' does not support simulation of noise types:{sep}{', '.join(foreign)}.")
+
+    def set_config(self, cfg: SimConfig) -> None:
+        """Replace the noise configuration (backend.py:183-198)."""
+        self._require_simconfig(cfg, f"Object {cfg} is not a valid `SimConfig`.", "")
         self._hamiltonian.set_config(cfg.to_noise_model())
         self._config = cfg
 
     def add_config(self, config: SimConfig) -> None:
         """backend.py:200-238: merge another configuration; noise types that are new bring their parameters along,
         noise types present in both keep the former parameters."""
-        if not isinstance(config, SimConfig):
-            raise ValueError(f"Object {config} is not a valid `SimConfig`")
-        not_supported = set(config.noise) - config.supported_noises[self._hamiltonian._interaction]
-        if not_supported:
-            raise NotImplementedError(
-                f"Interaction mode '{self._hamiltonian._interaction}' does not"
-                " support simulation of noise types: "
-                f"{', '.join(not_supported)}."
-            )
+        self._require_simconfig(config, f"Object {config} is not a valid `SimConfig`", " ")
         params_of = {"SPAM": ("eta", "epsilon", "epsilon_prime"), "doppler": ("temperature",),
                      "amplitude": ("laser_waist", "amp_sigma"), "relaxation": ("relaxation_rate",),
                      "dephasing": ("dephasing_rate", "hyperfine_dephasing_rate"), "depolarizing": ("depolarizing_rate",),
@@ -212,43 +208,35 @@ class TorchEmulator:
             end_ts += [bisect_left(remaining_indices.numpy(), sl.tf) for sl in samples.slots]
         return sorted(end_ts)
 
-    def set_evaluation_times(self, value) -> None:
-        """backend.py:312-375."""
+    def _requested_times(self, value) -> Tensor:
+        """The times a caller asks for, before the two end points are added (backend.py:335-362): a label, a fraction of the
+        sampling times, or explicit times in us."""
         st = self._hamiltonian.sampling_times
+        wrong_label = "Wrong evaluation time label. It should be `Full`, `Minimal`, an array of times or a float between 0 and 1."
         if isinstance(value, str):
-            if value == "Full":
-                eval_times = torch.clone(st)
-            elif value == "Minimal":
-                eval_times = torch.tensor([], dtype=st.dtype)
-            else:
-                raise ValueError(
-                    "Wrong evaluation time label. It should "
-                    "be `Full`, `Minimal`, an array of times or" + " a float between 0 and 1."
-                )
-        elif isinstance(value, float):
-            if value > 1 or value <= 0:
+            if value not in ("Full", "Minimal"):
+                raise ValueError(wrong_label)
+            return torch.clone(st) if value == "Full" else torch.tensor([], dtype=st.dtype)
+        if isinstance(value, float):
+            if not 0 < value <= 1:
                 raise ValueError("evaluation_times float must be between 0 and 1.")
-            indices = torch.linspace(0, len(st) - 1, int(value * len(st)), dtype=torch.int)
-            eval_times = st[indices.long()]
-        elif isinstance(value, (list, tuple, Tensor)):
-            if torch.max(torch.as_tensor(value)) > self._tot_duration / 1000:
-                raise ValueError("Provided evaluation-time list extends " "further than sequence duration.")
-            if torch.min(torch.as_tensor(value)) < 0:
-                raise ValueError("Provided evaluation-time list contains " "negative values.")
-            eval_times = torch.as_tensor(value)  # the union below is taken in the caller's dtype, like the reference does
-            if not eval_times.is_floating_point():
-                eval_times = eval_times.to(torch.float64)
-        else:
-            raise ValueError(
-                "Wrong evaluation time label. It should "
-                "be `Full`, `Minimal`, an array of times or a " + "float between 0 and 1."
-            )
-        self._eval_times_array = (
-            torch.cat([eval_times.detach().cpu(), torch.tensor([0.0, self._tot_duration / 1000], dtype=eval_times.dtype)])
-            .unique()
-            .to(torch.float64)
-            .requires_grad_(False)
-        )
+            keep = torch.linspace(0, len(st) - 1, int(value * len(st)), dtype=torch.int)
+            return st[keep.long()]
+        if isinstance(value, (list, tuple, Tensor)):
+            times = torch.as_tensor(value)
+            if torch.max(times) > self._tot_duration / 1000:
+                raise ValueError("Provided evaluation-time list extends further than sequence duration.")
+            if torch.min(times) < 0:
+                raise ValueError("Provided evaluation-time list contains negative values.")
+            return times if times.is_floating_point() else times.to(torch.float64)  # (the union is taken in the caller's dtype)
+        raise ValueError(wrong_label)
+
+    def set_evaluation_times(self, value) -> None:
+        """Times at which the results are returned (backend.py:312-375): what was asked for plus t = 0 and the end of the
+        sequence, sorted, without duplicates."""
+        asked = self._requested_times(value).detach().cpu()
+        ends = torch.tensor([0.0, self._tot_duration / 1000], dtype=asked.dtype)
+        self._eval_times_array = torch.cat([asked, ends]).unique().to(torch.float64).requires_grad_(False)
         self._eval_times_instruction = value
 
     def build_operator(self, operations) -> Tensor:
@@ -453,8 +441,16 @@ class TorchEmulator:
         if (sampled.max_duration != self._tot_duration or tuple(register.qubit_ids) != tuple(self._register.qubit_ids)
                 or list(sampled.channels) != list(old.channels) or sampled.used_bases != old.used_bases
                 or sampled._slm_mask != old._slm_mask
+                or sampled._measurement != old._measurement
+                or not _same_field(sampled._magnetic_field, old._magnetic_field)
                 or any(sampled._ch_objs[c] != old._ch_objs[c] for c in sampled.channels)):
             return False
+        # what the constructor checks about targets and the register holds for a refreshed sequence as well
+        self._hamiltonian._device.validate_register(register)
+        ids = set(register.qubit_ids)
+        for ch, ch_samples in sampled.channel_samples.items():
+            if sampled._ch_objs[ch].addressing == "Local" and not set().union(*(slot.targets for slot in ch_samples.slots)) <= ids:
+                raise ValueError("The ids of qubits targeted in Local channels should be defined in register.")
         samples_list = []
         for ch, ch_samples in sampled.channel_samples.items():
             if sampled._ch_objs[ch].addressing == "Local":
@@ -470,12 +466,15 @@ class TorchEmulator:
         ham._dist_dict = {}
         ham._construct_hamiltonian()
         self.dist_dict = {}
+        # a fresh leaf for the evaluation times: with time_grad the old one has requires_grad set and would ACCUMULATE its
+        # gradient from epoch to epoch (the reference makes a new emulator, hence a new tensor, per epoch: model.py:405-414)
+        self._eval_times_array = self._eval_times_array.detach().clone()
         return True
 
     @classmethod
     def from_sequence(cls, sequence, sampling_rate: float = 1.0, config: Optional[SimConfig] = None,
                       evaluation_times: Union[float, str, Any] = "Full", with_modulation: bool = False,
-                      compute_device: Union[str, torch.device] = "cuda") -> "TorchEmulator":
+                      compute_device: Union[str, torch.device] = "cuda", xy_hermitian: Optional[bool] = None) -> "TorchEmulator":
         r"""backend.py:651-711."""
         native = isinstance(sequence, pulses.Sequence)
         if not native and not all(hasattr(sequence, a) for a in ("is_parametrized", "is_register_mappable", "_schedule",
@@ -498,4 +497,5 @@ class TorchEmulator:
         return cls(
             sampler(sequence, modulation=with_modulation,
                     extended_duration=sequence.get_duration(include_fall_time=with_modulation)),
-            sequence.register, sequence.device, sampling_rate, config, evaluation_times, compute_device=compute_device)
+            sequence.register, sequence.device, sampling_rate, config, evaluation_times, compute_device=compute_device,
+            xy_hermitian=xy_hermitian)

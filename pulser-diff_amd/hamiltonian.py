@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import itertools
 import math
+import warnings
 from math import floor
 from typing import Callable, Union
 
@@ -57,7 +58,9 @@ class Hamiltonian:
     """
 
     def __init__(self, samples_obj, qdict: dict, device, sampling_rate: float, config: NoiseModel,
-                 compute_device: Union[str, torch.device] = "cuda") -> None:
+                 compute_device: Union[str, torch.device] = "cuda", xy_hermitian: Union[bool, None] = None) -> None:
+        if xy_hermitian is not None:  # per-emulator choice of the XY exchange (default: the class attribute, i.e. the reference's form)
+            self.XY_HERMITIAN = bool(xy_hermitian)
         self.samples_obj = samples_obj
         self._qdict = {k: (v if isinstance(v, Tensor) else torch.as_tensor(v)).to(RD) for k, v in qdict.items()}
         self._device = device
@@ -85,59 +88,60 @@ class Hamiltonian:
     def config(self) -> NoiseModel:
         return self._config
 
+    def _refuse_unsupported_noise(self, cfg: NoiseModel) -> None:
+        """The three reasons a noise model is turned away: the interaction mode does not know it (hamiltonian.py:151-158), this
+        backend has no realisation for it, or the three-level basis is in use (hamiltonian.py:98-103; here for every noise type)."""
+        asked = set(cfg.noise_types)
+        outside_mode = asked - SUPPORTED_NOISES[self._interaction]
+        if outside_mode:
+            raise NotImplementedError(f"Interaction mode '{self._interaction}' does not support "
+                                      f"simulation of noise types: {', '.join(outside_mode)}.")
+        unrealised = asked - STOCHASTIC_NOISES - COLLAPSE_NOISES
+        if unrealised:
+            raise NotImplementedError(f"Noise types {sorted(unrealised)} are not implemented in the MI355X-native backend.")
+        if asked and self.basis_name == "all":
+            # (the stochastic noises and relaxation would need per-qubit tables / the doubled register on the two-qubit-per-atom code)
+            raise NotImplementedError(f"Cannot include {sorted(asked)[0]} noise in all-basis.")
+
     def set_config(self, cfg: NoiseModel) -> None:
-        """hamiltonian.py:145-168."""
+        """Install a noise model and rebuild the structured problem for it (hamiltonian.py:145-168)."""
         if not isinstance(cfg, NoiseModel):
             raise ValueError(f"Object {cfg} is not a valid `NoiseModel`.")
-        not_supported = set(cfg.noise_types) - SUPPORTED_NOISES[self._interaction]
-        if not_supported:
-            raise NotImplementedError(
-                f"Interaction mode '{self._interaction}' does not support "
-                f"simulation of noise types: {', '.join(not_supported)}."
-            )
-        unknown = set(cfg.noise_types) - STOCHASTIC_NOISES - COLLAPSE_NOISES
-        if unknown:
-            raise NotImplementedError(f"Noise types {sorted(unknown)} are not implemented in the MI355X-native backend.")
         if not hasattr(self, "basis_name"):
-            self._build_basis_and_op_matrices()
-        if self.basis_name == "all" and cfg.noise_types:
-            # hamiltonian.py:98-103 refuses dephasing / depolarizing / eff_noise in the all-basis; the stochastic noises and
-            # relaxation would need the per-qubit tables / the doubled register on the two-qubit-per-atom encoding
-            raise NotImplementedError(f"Cannot include {sorted(cfg.noise_types)[0]} noise in all-basis.")
+            self._select_basis()
+        self._refuse_unsupported_noise(cfg)
         self._config = cfg
-        if not ("SPAM" in cfg.noise_types and cfg.state_prep_error > 0):
-            self._bad_atoms = {qid: False for qid in self._qid_index}
+        # noise parameters that this model does not draw are pinned to "none" (they may be left over from the previous model)
+        prep_errors = "SPAM" in cfg.noise_types and cfg.state_prep_error > 0
+        if not prep_errors:
+            self._bad_atoms = dict.fromkeys(self._qid_index, False)
         if "doppler" not in cfg.noise_types:
-            self._doppler_detune = {qid: 0.0 for qid in self._qid_index}
+            self._doppler_detune = dict.fromkeys(self._qid_index, 0.0)
         self._construct_hamiltonian()
 
-    def _build_basis_and_op_matrices(self) -> None:
-        """hamiltonian.py:288-318.  The three two-level bases share one structure — a lowering operator |1><0| (sigma_gr /
-        sigma_hg / sigma_du) driven by 0.5*amp*exp(-i*phase) and a projector |0><0| (sigma_rr / sigma_gg / sigma_uu) weighted by
-        -0.5*det (hamiltonian.py:410-416) — so all of them run on the same kernels; they differ in the interaction term only."""
+    # level names of every basis, in the order that fixes the amplitude index (hamiltonian.py:288-318): level 0 is the one the
+    # detuning projector sits on, the drive lowers level 0 -> level 1 (c |1><0| + h.c., hamiltonian.py:410-416)
+    _LEVELS = {"XY": ("u", "d"), "ground-rydberg": ("r", "g"), "digital": ("g", "h"), "all": ("r", "g", "h")}
+
+    def _select_basis(self) -> None:
+        """Which levels the register has.  The three two-level bases share one structure (a lowering operator driven by
+        0.5*amp*exp(-i*phase), a projector weighted by -0.5*det) and so run on the same kernels; a sequence that drives BOTH the
+        ground-rydberg and the digital transition has three levels per atom and runs as two qubits per atom (embedded_three_level)."""
+        driven = set(self.samples_obj.used_bases)
         if self._interaction == "XY":
-            self.basis_name = "XY"
-            basis = ["u", "d"]
-            projectors = ["uu", "du", "ud", "dd"]
-        elif "digital" not in self.samples_obj.used_bases:
-            self.basis_name = "ground-rydberg"
-            basis = ["r", "g"]
-            projectors = ["gr", "rr", "gg"]
-        elif "ground-rydberg" not in self.samples_obj.used_bases:
-            self.basis_name = "digital"
-            basis = ["g", "h"]
-            projectors = ["hg", "hh", "gg"]
+            name = "XY"
+        elif {"ground-rydberg", "digital"} <= driven:
+            name = "all"
         else:
-            # ground-rydberg AND digital channels in one sequence: three levels per atom (hamiltonian.py:306-310).  The native
-            # solver runs them as TWO qubits per atom (embedded_three_level, below).
-            self.basis_name = "all"
-            basis = ["r", "g", "h"]
-            projectors = ["gr", "hg", "rr", "gg", "hh"]
-        self.dim = len(basis)
-        self.basis = {b: basis_state(self.dim, i) for i, b in enumerate(basis)}
+            name = "digital" if "digital" in driven else "ground-rydberg"
+        levels = self._LEVELS[name]
+        self.basis_name, self.dim = name, len(levels)
+        self.basis = {lv: basis_state(self.dim, k) for k, lv in enumerate(levels)}
+        # every |a><b| of the level set, addressed by the reference's names ("sigma_gr" = |g><r|), plus the identity
         self.op_matrix = {"I": torch.eye(self.dim).to_sparse()}
-        for proj in projectors:
-            self.op_matrix["sigma_" + proj] = (self.basis[proj[0]] * self.basis[proj[1]].mH).to_sparse()
+        for a in levels:
+            for b in levels:
+                self.op_matrix[f"sigma_{a}{b}"] = (self.basis[a] @ self.basis[b].mH).to_sparse()
 
     def _update_noise(self) -> None:
         """hamiltonian.py:270-286: new random noise parameters (badly prepared atoms, Doppler detunings)."""
@@ -157,37 +161,47 @@ class Hamiltonian:
             return "SPAM" in cfg.noise_types and cfg.state_prep_error > 0
         return True
 
+    def _beam_profile(self) -> dict:
+        """Relative amplitude of a global beam at every atom: Gaussian in the distance from the origin (hamiltonian.py:196-201)."""
+        waist = self._config.laser_waist
+        if waist is None:
+            return dict.fromkeys(self._qid_index, 1.0)
+        return {qid: math.exp(-((float(torch.linalg.norm(pos)) / float(waist)) ** 2)) for qid, pos in self._qdict.items()}
+
     def _extract_samples(self) -> None:
-        """hamiltonian.py:170-219: the samples dictionary, with the current noise realisation applied per qubit."""
+        """The per-ns samples of the current noise realisation (hamiltonian.py:170-219).  Without per-atom noise the channels stay
+        as pulser sampled them; otherwise every atom gets its own copy on which the realisation acts pulse by pulse: the atom's
+        Doppler shift on the detuning, and — global channels — one drawn amplitude factor per pulse times the beam profile at
+        the atom.  Badly prepared atoms see no pulse at all."""
         cfg = self._config
-        local_noises = self._local_noises()
-        samples = self.samples_obj.to_nested_dict(all_local=local_noises, samples_type="tensor")
-        if local_noises:
-            for basis in samples["Local"]:
-                for qid in samples["Local"][basis]:
-                    for qty in ("amp", "det", "phase"):
-                        samples["Local"][basis][qid][qty] = samples["Local"][basis][qid][qty].detach().clone()
-            for ch, ch_samples in self.samples_obj.channel_samples.items():
-                info = self.samples_obj._ch_objs[ch]
-                samples_dict = samples["Local"][info.basis]
-                for slot in ch_samples.slots:
-                    # one amplitude fluctuation per pulse, shared by its targets (drawn for every pulse, as the reference does)
-                    noise_amp_base = max(0.0, float(torch.normal(torch.tensor([1.0]), cfg.amp_sigma)))
-                    for qid in slot.targets:
-                        if "doppler" in cfg.noise_types:
-                            samples_dict[qid]["det"][slot.ti:slot.tf] += self._doppler_detune[qid]
-                        if "amplitude" in cfg.noise_types and info.addressing == "Global":  # Gaussian beam profile
-                            amp_fraction = 1.0
-                            if cfg.laser_waist is not None:
-                                r = float(torch.linalg.norm(self._qdict[qid]))
-                                amp_fraction = math.exp(-((r / float(cfg.laser_waist)) ** 2))
-                            samples_dict[qid]["amp"][slot.ti:slot.tf] *= noise_amp_base * amp_fraction
-            for basis in samples["Local"]:  # badly prepared atoms do not see the pulses
-                for qid in samples["Local"][basis]:
-                    if self._bad_atoms[qid]:
-                        for qty in ("amp", "det", "phase"):
-                            samples["Local"][basis][qid][qty] = torch.zeros_like(samples["Local"][basis][qid][qty])
+        per_atom = self._local_noises()
+        samples = self.samples_obj.to_nested_dict(all_local=per_atom, samples_type="tensor")
         self.samples = samples
+        if not per_atom:
+            return
+        local = samples["Local"]
+        for per_q in local.values():  # private copies: the realisation is written into them in place
+            for qid, qty in per_q.items():
+                per_q[qid] = {name: arr.detach().clone() for name, arr in qty.items()}
+        shift_det = "doppler" in cfg.noise_types
+        scale_amp = "amplitude" in cfg.noise_types
+        beam = self._beam_profile() if scale_amp else None
+        for ch, ch_samples in self.samples_obj.channel_samples.items():
+            info = self.samples_obj._ch_objs[ch]
+            per_q = local[info.basis]
+            # one amplitude factor per pulse, shared by its targets, never negative; drawn for every pulse of every channel
+            factors = torch.normal(torch.ones(max(len(ch_samples.slots), 1)), float(cfg.amp_sigma)).clamp_min(0.0).tolist()
+            for slot, factor in zip(ch_samples.slots, factors):
+                window = slice(slot.ti, slot.tf)
+                for qid in slot.targets:
+                    if shift_det:
+                        per_q[qid]["det"][window] += self._doppler_detune[qid]
+                    if scale_amp and info.addressing == "Global":
+                        per_q[qid]["amp"][window] *= factor * beam[qid]
+        for per_q in local.values():
+            for qid in per_q:
+                if self._bad_atoms[qid]:
+                    per_q[qid] = {name: torch.zeros_like(arr) for name, arr in per_q[qid].items()}
 
     def noisy_batch_tables(self, n_runs: int, bad_atoms: Union[list, None] = None):
         """Coefficient tables of ``n_runs`` noise realisations as ONE batch: (amp_tables [R, K_a, n], det_tables
@@ -222,35 +236,41 @@ class Hamiltonian:
         return (amp[:, ka].contiguous().to(dev), det[:, kd].contiguous().to(dev), tuple(1 << j for j in ka),
                 tuple(1 << j for j in kd))
 
+    def _site_operator(self, operator) -> Tensor:
+        if not isinstance(operator, str):
+            return operator
+        if operator not in self.op_matrix:
+            raise ValueError(f"{operator} is not a valid operator")
+        return self.op_matrix[operator]
+
+    def _embed(self, site_ops: dict) -> Tensor:
+        """Tensor product over the register with `site_ops[k]` on atom k and the identity elsewhere."""
+        identity = self.op_matrix["I"]
+        return kron(*[site_ops.get(k, identity) for k in range(self._size)])
+
     def build_operator(self, operations: Union[list, tuple]) -> Tensor:
-        """hamiltonian.py:221-268 (explicit operator; small registers only)."""
+        """An explicit operator from ``[(operator, atom ids | "global"), ...]`` (hamiltonian.py:221-268; small registers only).
+        The entries act together as ONE tensor product; an entry addressed to "global" instead yields the sum of that operator
+        over all atoms — and, as in the reference, ends the evaluation there."""
         if self._size > MAX_EXPLICIT_QUBITS:
             raise ValueError(f"Explicit operators are limited to {MAX_EXPLICIT_QUBITS} qubits; use DiagonalObservable.")
-        op_list = [self.op_matrix["I"] for _ in range(self._size)]
-        if not isinstance(operations, list):
-            operations = [operations]
-        for operator, qubits in operations:
-            if qubits == "global":
-                mats = [self.build_operator([(operator, [q_id])]) for q_id in self._qdict]
-                out = mats[0]
-                for m in mats[1:]:
-                    out = out + m
-                return out
-            qubits_set = set(qubits)
-            if len(qubits_set) < len(qubits):
+        entries = operations if isinstance(operations, list) else [operations]
+        placed: dict = {}
+        for operator, where in entries:
+            if where == "global":
+                single = self._site_operator(operator)
+                terms = [self._embed({k: single}) for k in range(self._size)]
+                return sum(terms[1:], terms[0])
+            ids = list(where)
+            if len(set(ids)) != len(ids):
                 raise ValueError("Duplicate atom ids in argument list.")
-            if not qubits_set.issubset(self._qdict.keys()):
-                raise ValueError("Invalid qubit names: " f"{qubits_set - self._qdict.keys()}")
-            if isinstance(operator, str):
-                try:
-                    operator = self.op_matrix[operator]
-                except KeyError:
-                    raise ValueError(f"{operator} is not a valid operator")
-            for qubit in qubits:
-                op_list[self._qid_index[qubit]] = operator
-        return kron(*op_list)
+            strangers = set(ids) - self._qdict.keys()
+            if strangers:
+                raise ValueError("Invalid qubit names: " f"{strangers}")
+            single = self._site_operator(operator)
+            placed.update({self._qid_index[q]: single for q in ids})
+        return self._embed(placed)
 
-    # ------------------------------------------------------------------------------------------------------
     def _construct_hamiltonian(self, update: bool = True) -> None:
         """hamiltonian.py:320-497 for the ising / ground-rydberg mode: structure instead of matrices."""
         if update:
@@ -379,6 +399,7 @@ class Hamiltonian:
     # Waals operator but leaves the XY exchange ONE-DIRECTIONAL (|d u> -> |u d> only): a non-Hermitian generator.  The
     # upstream QutipEmulator adds the Hermitian conjugate.  Set it to True for the physical exchange U (s+s- + s-s+).
     XY_HERMITIAN = False
+    _warned_xy = False
     MAX_XY_QUBITS = 8  # the library takes up to RYDIFF_MAX_PAIR_TERMS = 28 dense two-qubit terms
 
     def _xy_pair_terms(self) -> tuple:
@@ -405,6 +426,12 @@ class Hamiltonian:
             block[1, 2] = j  # |u_q1 d_q2><d_q1 u_q2|: own = (u, d) = 1, source = (d, u) = 2
             if self.XY_HERMITIAN:
                 block[2, 1] = j
+            elif j != 0.0 and not Hamiltonian._warned_xy:
+                Hamiltonian._warned_xy = True
+                warnings.warn("XY mode: the exchange term is applied as the reference writes it (2 * int_mat without its adjoint, "
+                              "pulser_diff/hamiltonian.py:536): one-directional, the generator is not Hermitian and the norm is not "
+                              "conserved.  Set pulser_diff_amd.hamiltonian.Hamiltonian.XY_HERMITIAN = True (or pass "
+                              "xy_hermitian=True to TorchEmulator) for the physical exchange.", stacklevel=2)
             if j != 0.0:
                 terms.append((a, b, block.numpy()))
         return tuple(terms)

@@ -510,3 +510,57 @@ def test_integration_document_mirrors_the_abi_structs():
     info = txt[txt.index("class RydPlanInfo(ctypes.Structure)"):]
     info = info[:info.index("]")]
     assert re.findall(r'\("(\w+)",', info) == [f[0] for f in _native.RydPlanInfo._fields_]
+
+
+def test_xy_exchange_form_is_a_constructor_choice_and_the_literal_form_warns():
+    """the reference's XY generator is one-directional (2 * int_mat without its adjoint); that literal form stays the
+    default for parity but is announced, and the physical exchange is a constructor option instead of a class attribute."""
+    import warnings
+
+    import pulser_diff_amd as P
+    from pulser_diff_amd import pulses as pl
+    from pulser_diff_amd.hamiltonian import Hamiltonian
+
+    def build(**kw):
+        seq = pl.Sequence(pl.Register.from_coordinates([[0.0, 0.0], [6.5, 1.0]]), pl.MockDevice)
+        seq.declare_channel("g", "mw_global")
+        seq.add(pl.Pulse.ConstantPulse(40, 3.0, 1.0, 0.0), "g")
+        return P.TorchEmulator.from_sequence(seq, compute_device="cpu", **kw)
+
+    Hamiltonian._warned_xy = False
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        lit = build()
+        assert any("not Hermitian" in str(w.message) for w in caught)
+    h = lit.get_hamiltonian(10).to_dense()
+    assert (h - h.mH).abs().max() > 1.0
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        phys = build(xy_hermitian=True)
+        assert not any("not Hermitian" in str(w.message) for w in caught)
+    h = phys.get_hamiltonian(10).to_dense()
+    assert (h - h.mH).abs().max() < 1e-12
+    assert Hamiltonian.XY_HERMITIAN is False  # the class default is untouched
+
+
+def test_refreshed_emulator_gets_a_fresh_time_leaf_and_compares_measurement_and_field():
+    """a persistent emulator must not accumulate the evaluation-time gradient over epochs, and a sequence whose
+    measurement basis or magnetic field changed is a different structure (the caller then builds a new emulator)."""
+    import pulser_diff_amd as P
+    from pulser_diff_amd import pulses as pl
+
+    def seq_for(field=None, basis="mw_global"):
+        seq = pl.Sequence(pl.Register.from_coordinates([[0.0, 0.0], [6.5, 1.0]]), pl.MockDevice)
+        seq.declare_channel("g", basis)
+        if field is not None:
+            seq.set_magnetic_field(*field)
+        seq.add(pl.Pulse.ConstantPulse(40, 3.0, 1.0, 0.0), "g")
+        return seq
+
+    sim = P.TorchEmulator.from_sequence(seq_for((0.0, 1.0, 0.3)), compute_device="cpu")
+    leaf = sim._eval_times_array
+    leaf.requires_grad_(True)
+    assert sim.refresh_from_sequence(seq_for((0.0, 1.0, 0.3)))
+    assert sim._eval_times_array is not leaf and not sim._eval_times_array.requires_grad
+    assert torch.equal(sim._eval_times_array, leaf.detach())
+    assert not sim.refresh_from_sequence(seq_for((0.0, 0.0, 1.0)))   # another field: another interaction
