@@ -122,7 +122,7 @@ typedef struct RydProblem {
      * (B * 2^N <= 2^18, with gradients 2^19) and the chained passes beyond.  Results do not depend on the variant beyond rounding. */
     int32_t kernel_variant;
 
-    /* STATE-SHARDED forward runs (BASELINE config 5; the reference has no counterpart: it keeps the whole
+    /* STATE-SHARDED runs (BASELINE config 5; the reference has no counterpart: it keeps the whole
      * state in one process).  shard_bits = g > 0: the top g qubits (qubits 0..g-1 = the top g bits of the amplitude index)
      * select the RANK; every rank owns a contiguous slab of 2^(N-g) amplitudes.  n_qubits, the masks and u_pairs describe the
      * WHOLE register; `batch` = number of ranks whose slabs are part of THIS call, rank ids shard_rank_first ... + batch - 1,
@@ -138,7 +138,13 @@ typedef struct RydProblem {
      *     the first launch that reads shard_recv[] — make `stream` wait for those receives there.  The library runs the whole
      *     trajectory (every step, every factor) in ONE call and never touches the transport itself (torch.distributed /
      *     RCCL stay with the caller).  A non-zero return aborts the run with RYDIFF_EHIP.
-     * Forward only (need_tape = 0, no rydiff_backward), no pair terms, 1 <= N-g, N <= RYDIFF_MAX_QUBITS. */
+     * GRADIENTS (round 3): rydiff_forward with need_tape (the slabs' trajectory in the workspace tape) followed by rydiff_backward runs
+     * the whole reverse sweep natively as well.  The cotangent slabs take the SAME exchange (shard_exchange is called for them exactly as
+     * for the state slabs, phase 0 / phase 1), the drive gradients of the rank qubits are contracted with the partner slabs inside the
+     * completing launch, grad_expect is [n_obs][n_tsave][batch] (the cotangent of every slab's partial sum: normally the same number for
+     * all slabs) and g_amp / g_det / g_u receive this call's PARTIAL sums (the caller adds them over the ranks: one all-reduce of the
+     * tiny arrays); g_psi0 is [batch][2^(N-g)].  g_tsave is not available (RYDIFF_ENOTIMPL).
+     * No pair terms, 1 <= N-g, N <= RYDIFF_MAX_QUBITS. */
     int32_t shard_bits;
     int32_t shard_rank_first;
     void* const* shard_recv;

@@ -144,9 +144,9 @@ __device__ __forceinline__ void park2(double v0, double v1, double* red, int slo
         v0 += __shfl_down(v0, off, 64);
         v1 += __shfl_down(v1, off, 64);
     }
-    if ((threadIdx.x & 63) == 0) {
-        red[slot0 * NW + (threadIdx.x >> 6)] = v0;
-        red[slot1 * NW + (threadIdx.x >> 6)] = v1;
+    if ((threadIdx.x & 63) == 0) {  // (+=: a slot may take several contributions per launch; each wave owns its entry)
+        red[slot0 * NW + (threadIdx.x >> 6)] += v0;
+        red[slot1 * NW + (threadIdx.x >> 6)] += v1;
     }
 }
 
@@ -154,7 +154,7 @@ template <int NW>
 __device__ __forceinline__ void park1(double v0, double* red, int slot0) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v0 += __shfl_down(v0, off, 64);
-    if ((threadIdx.x & 63) == 0) red[slot0 * NW + (threadIdx.x >> 6)] = v0;
+    if ((threadIdx.x & 63) == 0) red[slot0 * NW + (threadIdx.x >> 6)] += v0;
 }
 
 // partner sums over the tile bits in `mask`:  ts[r] = sum of partners, ds[r] = sum(+partner if own bit set else -partner)
@@ -366,8 +366,9 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     for (int r = 0; r < R; ++r) acc[r] = ld(a.p + boff + xg[r]);
     // sharded runs: flips of the rank qubits = the partner slabs' complete v_{j-1} at the same local index, times
     // beta * (c or conj c).  Requested together with u and p so that all of a tile's global loads are in flight at once.
+    // (adjoint mode: u is the cotangent, fb = conj(beta): the same sum is the rank-qubit part of (gamma~ + beta~ H) mu)
     double2 remacc[R];
-    if (!BWD && a.has_p && a.sh_bits) {
+    if (a.has_p && a.completes && a.sh_bits) {
 #pragma unroll
         for (int r = 0; r < R; ++r) remacc[r] = make_double2(0.0, 0.0);
         const double* __restrict__ cfs = a.coef_fin + bt * a.coef_bstride;
@@ -492,6 +493,34 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
                 else park1<NW>(a.cb_fin_r * z1r - a.cb_fin_i * z1i, red, 2 * g);
             }
         }
+        if (a.completes && a.sh_bits) {  // rank-qubit flips: partner slabs (forward: of v_{j-1}; adjoint: of the cotangent)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                acc[r].x += remacc[r].x;
+                acc[r].y += remacc[r].y;
+            }
+            if (BWD && exact_fin) {
+                // exact drive gradients of the rank qubits: <F_k mu, x> with (F_k mu)(x) = the partner slab's mu at the same local
+                // index; plain sum z1 and signed sum z2 (sign + where the own rank bit is set), as for the tile bits above.  The
+                // partner values are re-read (L2 hits: requested a moment ago) rather than kept, so that the un-sharded adjoint —
+                // the headline path — pays no registers for this.
+                for (int k = 0; k < a.sh_bits; ++k) {
+                    const int g = a.sh_grp[k];
+                    if (g < 0) continue;
+                    const double2* __restrict__ src = a.sh_self ? a.u + size_t(unsigned(a.b_first) + (bl ^ (1u << k))) * a.dim : a.sh_rem[k] + size_t(bl) * a.dim;
+                    const double sgn = (rank >> k & 1u) ? 1.0 : -1.0;
+                    double z1r = 0.0, z1i = 0.0;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const double2 pv = src[xg[r]];
+                        z1r += pv.x * xf[r].x + pv.y * xf[r].y;
+                        z1i += pv.x * xf[r].y - pv.y * xf[r].x;
+                    }
+                    if (CPLX) park2<NW>(a.cb_fin_r * z1r - a.cb_fin_i * z1i, sgn * (a.cb_fin_r * z1i + a.cb_fin_i * z1r), red, 2 * g, 2 * g + 1);
+                    else park1<NW>(a.cb_fin_r * z1r - a.cb_fin_i * z1i, red, 2 * g);
+                }
+            }
+        }
         if constexpr (REC) {
             if (a.completes) {  // acc = mu' (before any injected cotangent), uu = mu, xf = the factor's input
                 // weights of d(x) in the gradient, Re(beta conj(mu) x): detuning group + U_ij accumulator
@@ -501,7 +530,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
                 for (int r = 0; r < R; ++r) {
                     const double pr = a.cb_fin_r * uu[r].x + a.cb_fin_i * uu[r].y, pi = a.cb_fin_i * uu[r].x - a.cb_fin_r * uu[r].y;
                     const double w = pr * xf[r].x - pi * xf[r].y;
-                    if (a.wtot) unsafeAtomicAdd(a.wtot + xg[r], w);
+                    if (a.wtot) unsafeAtomicAdd(a.wtot + (a.sh_bits ? boff : 0) + xg[r], w);
                     const double cnt = GD ? double(a.dcnt[0] - popc_i((xg[r] | rank_hi) & a.dmask[0])) : 0.0;
                     sgd += w * cnt;
                     if (!exact_fin) {  // Re <mu' - (gamma~ + beta~ d) mu, x>
@@ -519,13 +548,6 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = uu[r];
     }
-    if (!BWD && a.has_p && a.sh_bits) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            acc[r].x += remacc[r].x;
-            acc[r].y += remacc[r].y;
-        }
-    }
     if (BWD && a.has_p && (a.inj_gexp || a.inj_gstate)) {  // wave-uniform: the completed cotangent sits at a save point
         if (a.inj_gexp) {
             bool any = false;
@@ -534,7 +556,8 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     double wsum = 0.0;
-                    for (int o = 0; o < a.inj_n_obs; ++o) wsum += a.inj_gexp[o * a.inj_ostride + bt] * a.inj_obs[size_t(o) * a.dim + xg[r]];
+                    for (int o = 0; o < a.inj_n_obs; ++o)
+                        wsum += a.inj_gexp[o * a.inj_ostride + bt] * a.inj_obs[size_t(o) * a.obs_ostride + bt * a.obs_bstride + xg[r]];
                     acc[r].x += 2.0 * wsum * xf[r].x;
                     acc[r].y += 2.0 * wsum * xf[r].y;
                 }
@@ -588,7 +611,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
         for (int r = 0; r < R; ++r) {
             const double pr = a.cb_sta_r * acc[r].x + a.cb_sta_i * acc[r].y, pi = a.cb_sta_i * acc[r].x - a.cb_sta_r * acc[r].y;
             rr[r] = pr * xs[r].x - pi * xs[r].y;
-            if (a.wtot) unsafeAtomicAdd(a.wtot + xg[r], rr[r]);
+            if (a.wtot) unsafeAtomicAdd(a.wtot + (a.sh_bits ? boff : 0) + xg[r], rr[r]);
         }
         for (int g = 0; g < GD; ++g) {
             double sgd = 0.0;

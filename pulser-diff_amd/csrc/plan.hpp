@@ -406,7 +406,7 @@ inline size_t carve(Plan& pl, int tape_mode, bool need_backward, int chain_slots
     if (need_backward) {
         pl.off_chain = take(size_t(chain_slots > 0 ? chain_slots : 1) * pl.state_bytes);
         pl.off_ge = take(size_t(pl.Bc) * E * 64 /* kGradReplicas */ * (pl.NC + 1) * sizeof(double));
-        pl.off_wtot = take(pl.dim * sizeof(double));
+        pl.off_wtot = take(pl.dim * (pl.shard_bits ? size_t(pl.B) : 1) * sizeof(double));  // sharded: one weight slab per rank of the call
         pl.off_meta2 = take(std::max(E * 40, size_t(pl.T + 1) * sizeof(int32_t)));  // StageBwdDev records, or the save-point flags of the one-launch adjoint
     }
     return off;

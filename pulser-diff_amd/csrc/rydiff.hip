@@ -164,18 +164,24 @@ struct FactorBwdArgs {
     const double* inj_obs = nullptr;      // [n_obs][dim]
     int inj_n_obs = 0;
     long inj_ostride = 0;                 // n_tsave * B
+    long obs_bstride = 0, obs_ostride = 0;  // observable table: [n_obs][dim] (0, dim); sharded: one slab per rank (dim, B * dim)
+    // state-sharded run (ChainArgs documents the fields): the cotangent slabs of the partner ranks enter the adjoint matvec, and —
+    // through the re-indexed contraction below — the drive gradients of the rank qubits
+    int sh_bits = 0, sh_nl = 0, sh_rank_first = 0, sh_self = 0;
+    const double2* sh_rem[kShardMaxBits] = {};
+    int sh_grp[kShardMaxBits] = {};
 };
 
 // the injected cotangent at amplitude x of trajectory b (see FactorBwdArgs); wave-uniform control flow
 __device__ __forceinline__ double2 injected_cotangent(const double2* inj_gstate, const double* inj_gexp, const double* inj_obs,
-                                                      int n_obs, long ostride, uint32_t dim, int b, size_t boff, uint32_t x,
-                                                      const double2& psi) {
+                                                      int n_obs, long ostride, long obs_ostride, long obs_bstride, int b, size_t boff,
+                                                      uint32_t x, const double2& psi) {
     double2 add = make_double2(0.0, 0.0);
     if (inj_gexp) {
         double wsum = 0.0;
         for (int o = 0; o < n_obs; ++o) {
             const double ge = inj_gexp[o * ostride + b];
-            if (ge != 0.0) wsum += ge * inj_obs[size_t(o) * dim + x];
+            if (ge != 0.0) wsum += ge * inj_obs[size_t(o) * obs_ostride + size_t(b) * obs_bstride + x];
         }
         add.x = 2.0 * wsum * psi.x;
         add.y = 2.0 * wsum * psi.y;
@@ -275,7 +281,10 @@ __global__ void k_build_split(double* __restrict__ utt, double* __restrict__ vr,
 }
 
 // g_u[pair] = sum_x n_i n_j wtot[x]
-__global__ void k_ugrad(double* __restrict__ g_u, const double* __restrict__ wtot, int N, uint32_t dim) {
+// sharded runs (slabs > 0): wtot holds one slab of 2^nl weights per rank of the call; amplitude x of slab b sits at the global index
+// x | (rank_first + b) << nl — every rank adds its part, the caller sums g_u over the ranks
+__global__ void k_ugrad(double* __restrict__ g_u, const double* __restrict__ wtot, int N, uint32_t dim, int slabs = 0, int nl = 0,
+                        int rank_first = 0) {
     __shared__ double lds[8];
     const int pair = blockIdx.y;
     int i = 0, rem = pair;
@@ -286,8 +295,16 @@ __global__ void k_ugrad(double* __restrict__ g_u, const double* __restrict__ wto
     const int j = i + 1 + rem;
     const uint32_t mi = 1u << (N - 1 - i), mj = 1u << (N - 1 - j);
     double s = 0.0;
-    for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < dim; x += gridDim.x * blockDim.x)
-        if (!(x & mi) && !(x & mj)) s += wtot[x];
+    if (slabs > 0) {
+        for (int b = 0; b < slabs; ++b) {
+            const uint32_t hi = uint32_t(rank_first + b) << nl;
+            for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < dim; x += gridDim.x * blockDim.x)
+                if (!((x | hi) & mi) && !((x | hi) & mj)) s += wtot[size_t(b) * dim + x];
+        }
+    } else {
+        for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < dim; x += gridDim.x * blockDim.x)
+            if (!(x & mi) && !(x & mj)) s += wtot[x];
+    }
     block_atomic_add(s, g_u + pair, lds);
 }
 
@@ -502,7 +519,9 @@ __global__ __launch_bounds__(256) void k_factor_bwd_direct(FactorBwdArgs a) {
     const double* __restrict__ cf = a.coef + blockIdx.y * a.coef_bstride;
     double* __restrict__ ge = a.ge + blockIdx.y * a.ge_bstride + (blockIdx.x % kGradReplicas) * a.ge_rstride;
     const uint32_t xs = live ? x : 0u;
-    const double d = diag_value(a.udiag, cf, a.g, xs);
+    const unsigned rank = unsigned(a.sh_rank_first) + blockIdx.y;
+    const uint32_t xglob = a.sh_bits ? (xs | (rank << a.sh_nl)) : xs;  // sharded: the diagonal lives at the global index
+    const double d = diag_value(a.udiag + (a.sh_bits ? boff : 0), cf, a.g, xs, xglob);
     double2 gy = gin[xs];
     double2 xi = xin[xs];
     if (!live) {
@@ -515,7 +534,7 @@ __global__ __launch_bounds__(256) void k_factor_bwd_direct(FactorBwdArgs a) {
     // a_ = beta * conj(gy)
     const double pr = a.br * gy.x + a.bi * gy.y, pi = a.bi * gy.x - a.br * gy.y;
     const double r = pr * xi.x - pi * xi.y;  // Re(beta conj(gy) xi)
-    if (a.wtot && live) unsafeAtomicAdd(a.wtot + x, r);
+    if (a.wtot && live) unsafeAtomicAdd(a.wtot + (a.sh_bits ? boff : 0) + x, r);  // sharded: one weight slab per rank (k_ugrad)
     for (int q = 0; q < a.g.ga; ++q) {
         double s1r = 0.0, s1i = 0.0, s0r = 0.0, s0i = 0.0;  // partner sums of gin: for the matvec AND for the contraction
         uint32_t m = a.g.amask[q];
@@ -525,6 +544,15 @@ __global__ __launch_bounds__(256) void k_factor_bwd_direct(FactorBwdArgs a) {
             if (!flip_acts(a.g.cond, q, xs, bit)) continue;
             const double2 p = gin[xs ^ bit];
             if (xs & bit) {
+                s1r += p.x; s1i += p.y;
+            } else {
+                s0r += p.x; s0i += p.y;
+            }
+        }
+        for (int k = 0; k < a.sh_bits; ++k) {  // flips of the rank qubits of this group: the partner ranks' cotangent slabs
+            if (a.sh_grp[k] != q) continue;
+            const double2 p = a.sh_self ? a.gin[size_t(blockIdx.y ^ (1u << k)) * a.dim + xs] : a.sh_rem[k][boff + xs];
+            if (rank >> k & 1u) {
                 s1r += p.x; s1i += p.y;
             } else {
                 s0r += p.x; s0i += p.y;
@@ -553,7 +581,7 @@ __global__ __launch_bounds__(256) void k_factor_bwd_direct(FactorBwdArgs a) {
         block_atomic_add(gim, ge + a.g.ga + q, lds);
     }
     for (int q = 0; q < a.g.gd; ++q) {
-        const double v = live ? r * double(a.g.dcnt[q] - popc_i(x & a.g.dmask[q])) : 0.0;
+        const double v = live ? r * double(a.g.dcnt[q] - popc_i(xglob & a.g.dmask[q])) : 0.0;
         block_atomic_add(v, ge + 2 * a.g.ga + q, lds);
     }
     if (a.pair.n && live) {  // conj(beta) * (pair terms)^dagger applied to the cotangent
@@ -562,7 +590,8 @@ __global__ __launch_bounds__(256) void k_factor_bwd_direct(FactorBwdArgs a) {
         ai += a.br * pv.y - a.bi * pv.x;
     }
     if ((a.inj_gexp || a.inj_gstate) && live) {
-        const double2 add = injected_cotangent(a.inj_gstate, a.inj_gexp, a.inj_obs, a.inj_n_obs, a.inj_ostride, a.dim, blockIdx.y, boff, x, xi);
+        const double2 add = injected_cotangent(a.inj_gstate, a.inj_gexp, a.inj_obs, a.inj_n_obs, a.inj_ostride, a.obs_ostride, a.obs_bstride,
+                                               blockIdx.y, boff, x, xi);
         ar += add.x;
         ai += add.y;
     }
@@ -647,7 +676,8 @@ __global__ __launch_bounds__(256) void k_factor_bwd_direct_global(FactorBwdArgs 
     const double fr = cr * gsr - ci * gdi, fi = cr * gsi + ci * gdr;
     double2 go = make_double2(dr * gy.x - di * gy.y + a.br * fr + a.bi * fi, dr * gy.y + di * gy.x + a.br * fi - a.bi * fr);
     if (a.inj_gexp || a.inj_gstate) {
-        const double2 add = injected_cotangent(a.inj_gstate, a.inj_gexp, a.inj_obs, a.inj_n_obs, a.inj_ostride, a.dim, blockIdx.y, boff, x, xi);
+        const double2 add = injected_cotangent(a.inj_gstate, a.inj_gexp, a.inj_obs, a.inj_n_obs, a.inj_ostride, a.obs_ostride, a.obs_bstride,
+                                               blockIdx.y, boff, x, xi);
         go.x += add.x;
         go.y += add.y;
     }
@@ -758,7 +788,7 @@ __global__ __launch_bounds__(256) void k_expect_diag(const double2* __restrict__
 __global__ __launch_bounds__(256) void k_inject(double2* __restrict__ lam, const double2* __restrict__ gstate,
                                                 const double2* __restrict__ psi, const double* __restrict__ obs,
                                                 const double* __restrict__ gexp, int n_obs, int n_tsave, int k, int B,
-                                                uint32_t dim, int overwrite) {
+                                                uint32_t dim, int overwrite, long obs_ostride, long obs_bstride) {
     const uint32_t x = blockIdx.x * 256u + threadIdx.x;
     if (x >= dim) return;
     const int b = blockIdx.y;
@@ -771,7 +801,7 @@ __global__ __launch_bounds__(256) void k_inject(double2* __restrict__ lam, const
     }
     if (gexp && n_obs > 0) {
         double wsum = 0.0;
-        for (int o = 0; o < n_obs; ++o) wsum += gexp[(size_t(o) * n_tsave + k) * B + b] * obs[size_t(o) * dim + x];
+        for (int o = 0; o < n_obs; ++o) wsum += gexp[(size_t(o) * n_tsave + k) * B + b] * obs[size_t(o) * obs_ostride + size_t(b) * obs_bstride + x];
         const double2 v = psi[o_];
         acc.x += 2.0 * wsum * v.x;
         acc.y += 2.0 * wsum * v.y;
@@ -1220,8 +1250,8 @@ int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_
     rc = finish_runtime(rt, lo, hi);
     if (rc) return rc;
     Plan& pl = rt.pl;
-    if (pl.shard_bits && (need_tape || need_backward))
-        return fail(RYDIFF_ENOTIMPL, "state-sharded runs are forward only here (gradients: pulser-diff_amd/sharded.py grad_distributed)");
+    if (pl.shard_bits && pl.n_pair)
+        return fail(RYDIFF_ENOTIMPL, "state-sharded runs do not take dense pair terms");
     if (pl.shard_bits) rt.generic_direct = true;  // (the unrolled direct kernels know nothing about rank qubits)
     if (need_tape == 2 && !full_tape_possible(pl)) need_tape = 1;  // full tape only with chained passes
     rt.prefer_direct = few_tiles(rt, need_backward || need_tape != 0);
@@ -1695,6 +1725,8 @@ int run_chain_bwd(const Runtime& rt, char* ws, const std::vector<ChainItem>& ite
     std::vector<KernelStep> ks;
     chain_schedule(pl.NL, rt.force_three, M, ks);
     const double2* cur = lam_in;
+    int rcx = shard_signal(rt, 0, cur);  // sharded: the partners need the incoming cotangent for the first completing launch
+    if (rcx) return rcx;
     auto ppsel = [&](size_t k) { return bs.xcd ? pp[0] : pp[k & 1]; };
     // adjoint factor index a = 0..M-1 corresponds to forward factor f = M-1-a
     for (size_t k = 0; k < ks.size(); ++k) {
@@ -1743,10 +1775,16 @@ int run_chain_bwd(const Runtime& rt, char* ws, const std::vector<ChainItem>& ite
                 if (rc) return rc;
             }
         }
-        int rc = launch_chain(rt, ws, cs, bs, inj, stream);
+        int rc = (cs.has_p && st.completes) ? shard_signal(rt, 1, nullptr) : RYDIFF_OK;  // this launch reads the partners' copies of `cur`
+        if (rc) return rc;
+        rc = launch_chain(rt, ws, cs, bs, inj, stream);
         if (rc) return rc;
         if (cs.has_p && st.completes) {
             cur = cs.v_out;  // complete cotangent at the INPUT of forward factor f = output of forward factor f-1
+            if (k + 1 < ks.size()) {  // the next completing launch needs the partners' copies of this cotangent
+                rc = shard_signal(rt, 0, cur);
+                if (rc) return rc;
+            }
             const int f = M - 1 - st.fin;
             if (f >= 1 && items[f].stage != items[f - 1].stage) {
                 rc = on_stage_end(items[f - 1].stage, cur, xs[f]);
@@ -2233,9 +2271,14 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
     inj.gexp = have_gexp ? grad_expect : nullptr;
     inj.obs = obs;
     inj.n_obs = have_gexp ? pl.n_obs : 0;
+    // observable table [n_obs][dim]; state-sharded runs: one slab per rank of the call, [n_obs][B][dim]
+    const long obs_bstride = pl.shard_bits ? long(pl.dim) : 0;
+    const long obs_ostride = pl.shard_bits ? long(pl.B) * long(pl.dim) : long(pl.dim);
+    if (pl.shard_bits && g_tsave)
+        return fail(RYDIFF_ENOTIMPL, "state-sharded runs: no gradient w.r.t. the evaluation times (pass g_tsave = NULL)");
 
     HIP_TRY(hipMemsetAsync(ge, 0, size_t(pl.Bc) * E * ge_rec * sizeof(double), stream));
-    if (wtot) HIP_TRY(hipMemsetAsync(wtot, 0, pl.dim * sizeof(double), stream));
+    if (wtot) HIP_TRY(hipMemsetAsync(wtot, 0, pl.dim * (pl.shard_bits ? size_t(pl.B) : 1) * sizeof(double), stream));
     dim3 grid(unsigned((pl.dim + 255) / 256), pl.B);
     int cl = 0;
     // where the state at tsave[k] lives: one entry per tsave, or (full tape) one entry per factor pass
@@ -2308,7 +2351,7 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
         // adjoint state there (fused injection: no separate launches, and no host-side look at grad_expect)
         hipLaunchKernelGGL(k_inject, grid, dim3(256), 0, stream, lam[cl], gst ? gst + size_t(pl.T) * sv : nullptr,
                            state_at(pl.T), obs, have_gexp ? grad_expect : nullptr, pl.n_obs, pl.T + 1, pl.T, pl.B,
-                           uint32_t(pl.dim), 1);
+                           uint32_t(pl.dim), 1, obs_ostride, obs_bstride);
         LAUNCH_CHECK();
     }
 
@@ -2371,7 +2414,10 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
             } else {
                 for (int i = 1; i < M; ++i) {
                     double2* dst = chainbuf + size_t(i - 1) * sv;
-                    int rc2 = launch_factor(rt, ws, xs[i - 1], dst, chain[i - 1].stage, chain[i - 1].s, stream);
+                    int rc2 = shard_signal(rt, 0, xs[i - 1]);  // (sharded recompute: the partners need this factor input, this launch theirs)
+                    if (!rc2) rc2 = shard_signal(rt, 1, nullptr);
+                    if (rc2) return rc2;
+                    rc2 = launch_factor(rt, ws, xs[i - 1], dst, chain[i - 1].stage, chain[i - 1].s, stream);
                     if (rc2) return rc2;
                     xs[i] = dst;
                 }
@@ -2408,6 +2454,20 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
                 ba.bi = it.s.bi;
                 ba.g = rt.garg;
                 ba.pair = rt.parg;
+                ba.obs_bstride = obs_bstride;
+                ba.obs_ostride = obs_ostride;
+                if (pl.shard_bits) {  // partner ranks' cotangent slabs (exchanged like the forward slabs: shard_signal)
+                    ba.sh_bits = pl.shard_bits;
+                    ba.sh_nl = pl.NL;
+                    ba.sh_rank_first = pl.rank_first;
+                    ba.sh_self = pl.shard_self ? 1 : 0;
+                    for (int kq = 0; kq < pl.shard_bits; ++kq) ba.sh_rem[kq] = pl.shard_self ? nullptr : static_cast<const double2*>(rt.shard_recv[kq]);
+                    shard_groups(pl, ba.sh_grp);
+                    for (int q = 0; q < ba.g.ga; ++q) ba.g.amask[q] &= uint32_t(pl.dim - 1);  // in-slab flips only (as in launch_factor)
+                    int rcs = shard_signal(rt, 0, lam[cl]);  // the partners need this rank's cotangent ...
+                    if (!rcs) rcs = shard_signal(rt, 1, nullptr);  // ... and this launch reads theirs
+                    if (rcs) return rcs;
+                }
                 if (save_k[i - 1] >= 0 && inj.any()) {  // gout is the cotangent at save point k: add what is injected there
                     const int ks = save_k[i - 1];
                     ba.inj_gstate = inj.gstate ? inj.gstate + size_t(ks) * sv : nullptr;
@@ -2485,7 +2545,8 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
         if (npairs > 0) {
             HIP_TRY(hipMemsetAsync(g_u, 0, size_t(npairs) * 8, stream));
             const unsigned nb = unsigned(std::min<size_t>((pl.dim + 255) / 256, 256));
-            hipLaunchKernelGGL(k_ugrad, dim3(nb, npairs), dim3(256), 0, stream, g_u, wtot, pl.N, uint32_t(pl.dim));
+            hipLaunchKernelGGL(k_ugrad, dim3(nb, npairs), dim3(256), 0, stream, g_u, wtot, pl.N, uint32_t(pl.dim),
+                               pl.shard_bits ? pl.B : 0, pl.NL, pl.rank_first);
             LAUNCH_CHECK();
         }
     }

@@ -324,13 +324,11 @@ def run_distributed(prob: ShardedProblem, psi0_local: Tensor, tsave, group=None,
 # natively driven forward run: ONE call of rydiff_forward runs every step and every factor pass of the sharded trajectory
 # (include/rydiff.h, RydProblem.shard_bits); Python only posts the slab exchanges when the library asks for them.
 # ---------------------------------------------------------------------------------------------------------------------
-def _native_forward(prob: ShardedProblem, psi_slabs: Tensor, tsave, rank_first: int, obs_slabs: Optional[Tensor],
-                    recv: Optional[list], exchange: Optional[Callable], lookup: Optional[list] = None) -> tuple[Tensor, Optional[Tensor], dict]:
-    """psi_slabs: (ranks_here, 2^(N-g)) on the GPU; obs_slabs: (ranks_here, 2^(N-g)) or None.  Returns the final slabs, the
-    PARTIAL <O>(t_k) summed over the slabs of this call (n_tsave,) and the plan statistics."""
+def _native_problem(prob: ShardedProblem, psi_slabs: Tensor, tsave, rank_first: int, obs_slabs: Optional[Tensor],
+                    recv: Optional[list], exchange: Optional[Callable]):
+    """The RydProblem of a state-sharded call (slabs of this call = its "trajectories") and the objects that must outlive it."""
     from . import _native
 
-    L = _native.lib()
     dev = psi_slabs.device
     ts = np.ascontiguousarray(np.asarray(tsave, dtype=np.float64))
     amp = torch.as_tensor(np.ascontiguousarray(prob.amp_tables, dtype=np.complex128)).reshape(1, -1, prob.amp_tables.shape[-1]).to(dev) \
@@ -359,7 +357,9 @@ def _native_forward(prob: ShardedProblem, psi_slabs: Tensor, tsave, rank_first: 
         obs = obs_slabs.to(torch.float64).contiguous().reshape(1, ranks_here, dloc)
         p.n_obs, p.obs_diag = 1, obs.data_ptr()
     p.kernel_variant = _native.default_kernel_variant()
-    p.shard_bits, p.shard_rank_first, p.final_state_only = prob.n_gpu_bits, rank_first, 1
+    p.shard_bits, p.shard_rank_first = prob.n_gpu_bits, rank_first
+    # drives without phase: only dL/dRe(amp) exists, and the adjoint passes may skip the signed partner sums (single-tape-read form)
+    p.real_amp_grad = int(not np.iscomplexobj(prob.amp_tables) or not np.any(np.asarray(prob.amp_tables).imag))
     keep = [amp, det, u, amp_masks, det_masks, ts, obs]
     if recv is not None:
         ptrs = (ctypes.c_void_p * len(recv))(*[r.data_ptr() for r in recv])
@@ -367,6 +367,20 @@ def _native_forward(prob: ShardedProblem, psi_slabs: Tensor, tsave, rank_first: 
         p.shard_recv = ctypes.cast(ptrs, ctypes.c_void_p)
         p.shard_exchange = ctypes.cast(cb, ctypes.c_void_p)
         keep += [ptrs, cb]
+    return p, psi, ts, amp, det, u, obs, keep
+
+
+def _native_forward(prob: ShardedProblem, psi_slabs: Tensor, tsave, rank_first: int, obs_slabs: Optional[Tensor],
+                    recv: Optional[list], exchange: Optional[Callable], lookup: Optional[list] = None) -> tuple[Tensor, Optional[Tensor], dict]:
+    """psi_slabs: (ranks_here, 2^(N-g)) on the GPU; obs_slabs: (ranks_here, 2^(N-g)) or None.  Returns the final slabs, the
+    PARTIAL <O>(t_k) summed over the slabs of this call (n_tsave,) and the plan statistics."""
+    from . import _native
+
+    L = _native.lib()
+    p, psi, ts, _amp, _det, _u, obs, keep = _native_problem(prob, psi_slabs, tsave, rank_first, obs_slabs, recv, exchange)
+    p.final_state_only = 1
+    dev = psi.device
+    ranks_here = psi.shape[0]
     with torch.cuda.device(dev):
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         scratch = torch.empty(_native.PLAN_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
@@ -386,6 +400,50 @@ def _native_forward(prob: ShardedProblem, psi_slabs: Tensor, tsave, rank_first: 
     return final, (expect[0].sum(dim=1) if expect is not None else None), stats
 
 
+def _native_value_and_grad(prob: ShardedProblem, psi_slabs: Tensor, tsave, rank_first: int, obs_slabs: Tensor, grad_expect,
+                           recv: Optional[list], exchange: Optional[Callable], lookup: Optional[list] = None, tape: int = 1) -> dict:
+    """Forward + adjoint sweep of a state-sharded run in TWO native calls (rydiff_forward with the trajectory kept in the workspace
+    tape, rydiff_backward): the library walks every factor of the reverse sweep itself — the cotangent slabs take the same
+    hypercube exchange as the state slabs (same callback), the drive gradients of the rank qubits are contracted with the partner
+    slabs inside the completing launch.  Returns this call's PARTIAL sums: expect (n_tsave,), g_amp, g_det, g_u (to be summed over
+    the ranks by the caller) and the cotangent slabs w.r.t. psi0."""
+    from . import _native
+
+    L = _native.lib()
+    p, psi, ts, amp, det, u, obs, keep = _native_problem(prob, psi_slabs, tsave, rank_first, obs_slabs, recv, exchange)
+    dev = psi.device
+    ranks_here = psi.shape[0]
+    n_t = len(ts)
+    w = torch.as_tensor(np.asarray(grad_expect, dtype=np.float64)).to(dev)
+    gexp = w.reshape(1, n_t, 1).expand(1, n_t, ranks_here).contiguous()  # d loss / d <O>(t_k), the same for every slab's partial sum
+    with torch.cuda.device(dev):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        scratch = torch.empty(_native.PLAN_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
+        info = _native.RydPlanInfo()
+        _native.check(L.rydiff_plan(ctypes.byref(p), tape, 1, ctypes.c_void_p(scratch.data_ptr()), stream, ctypes.byref(info)))
+        workspace = torch.empty(info.workspace_bytes, dtype=torch.uint8, device=dev)
+        expect = torch.zeros(1, n_t, ranks_here, dtype=torch.float64, device=dev)
+        g_amp = torch.zeros_like(amp)
+        g_det = torch.zeros_like(det)
+        g_u = torch.zeros_like(u)
+        g_psi0 = torch.zeros_like(psi)
+        keep.append(workspace)
+        if lookup is not None:
+            lookup[:] = [psi, workspace]
+        _native.check(L.rydiff_forward(ctypes.byref(p), ctypes.byref(info), ctypes.c_void_p(psi.data_ptr()), None,
+                                       ctypes.c_void_p(expect.data_ptr()), ctypes.c_void_p(workspace.data_ptr()), workspace.numel(),
+                                       tape, stream))
+        _native.check(L.rydiff_backward(ctypes.byref(p), ctypes.byref(info), None, None, ctypes.c_void_p(gexp.data_ptr()),
+                                        ctypes.c_void_p(g_amp.data_ptr()) if amp.shape[1] else None,
+                                        ctypes.c_void_p(g_det.data_ptr()) if det.shape[1] else None,
+                                        ctypes.c_void_p(g_u.data_ptr()) if u.numel() else None, None, ctypes.c_void_p(g_psi0.data_ptr()),
+                                        ctypes.c_void_p(workspace.data_ptr()), workspace.numel(), tape, stream))
+        torch.cuda.current_stream(dev).synchronize()  # (the host-side arrays in `keep` may go once the queue has drained)
+    return {"expect": expect[0].sum(dim=1), "g_amp": g_amp[0], "g_det": g_det[0], "g_u": g_u, "g_psi0": g_psi0,
+            "stats": {"degree": info.degree, "total_factors": info.total_factors, "kernel_family": _native.KERNEL_FAMILIES[info.kernel_family],
+                      "kernel_fwd": info.kernel_fwd.decode(), "kernel_bwd": info.kernel_bwd.decode(), "tape_mode": info.tape_mode}}
+
+
 def run_virtual_native(prob: ShardedProblem, psi0: Tensor, tsave, obs_diag: Optional[Tensor] = None):
     """All 2^g ranks on this device, the whole trajectory in ONE native call (partners are read in place).
     Returns (final state (2^N,), <O>(t_k) or None, stats)."""
@@ -395,15 +453,13 @@ def run_virtual_native(prob: ShardedProblem, psi0: Tensor, tsave, obs_diag: Opti
     return final.reshape(-1), expect, stats
 
 
-def run_distributed_native(prob: ShardedProblem, psi0_local: Tensor, tsave, group=None, obs_diag_local: Optional[Tensor] = None):
-    """One process per GPU: the library runs the whole trajectory of this rank's slab in one call and asks — through the
-    exchange callback — for the hypercube slab exchange before every completing pass (one isend / irecv pair per partner =
-    one xGMI link each, posted together); <O>(t_k) is all-reduced once at the end.  Returns (final slab, <O>(t_k), stats)."""
+def _hypercube_exchange(prob: ShardedProblem, psi0_local: Tensor, rank: int, group):
+    """Receive buffers + the callback the library calls for the slab exchange of a run with one slab per process
+    (include/rydiff.h: RydProblem.shard_exchange): phase 0 posts one isend / irecv pair per hypercube neighbour (= one xGMI link
+    each, all in flight together), phase 1 waits for them before the first launch that reads the received slabs.  The slab to
+    send is identified by its device address inside the tensors of `lookup` (the state slabs, the workspace)."""
     import torch.distributed as dist
 
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-    if world != prob.world:
-        raise ValueError(f"world size {world} != 2^{prob.n_gpu_bits}")
     g = prob.n_gpu_bits
     recv = [torch.empty_like(psi0_local, dtype=torch.complex128) for _ in range(g)]  # recv[k]: slab of rank ^ (1 << k)
     state = {"works": [], "error": None, "staged": []}
@@ -445,6 +501,19 @@ def run_distributed_native(prob: ShardedProblem, psi0_local: Tensor, tsave, grou
             state["error"] = exc
             return 1
 
+    return recv, exchange, lookup, state
+
+
+def run_distributed_native(prob: ShardedProblem, psi0_local: Tensor, tsave, group=None, obs_diag_local: Optional[Tensor] = None):
+    """One process per GPU: the library runs the whole trajectory of this rank's slab in one call and asks — through the
+    exchange callback — for the hypercube slab exchange before every completing pass; <O>(t_k) is all-reduced once at the end.
+    Returns (final slab, <O>(t_k), stats)."""
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if world != prob.world:
+        raise ValueError(f"world size {world} != 2^{prob.n_gpu_bits}")
+    recv, exchange, lookup, state = _hypercube_exchange(prob, psi0_local, rank, group)
     try:
         final, expect, stats = _native_forward(prob, psi0_local.reshape(1, -1), tsave, rank,
                                                None if obs_diag_local is None else obs_diag_local.reshape(1, -1), recv, exchange, lookup)
@@ -460,6 +529,41 @@ def run_distributed_native(prob: ShardedProblem, psi0_local: Tensor, tsave, grou
 # ---------------------------------------------------------------------------------------------------------------------
 # gradients: exact discrete adjoint of the sharded factor chain
 # ---------------------------------------------------------------------------------------------------------------------
+def grad_virtual_native(prob: ShardedProblem, psi0: Tensor, tsave, obs_diag: Tensor, grad_expect) -> dict:
+    """Value and gradients of  sum_k grad_expect[k] <O>(t_k)  with all 2^g ranks on this device and the WHOLE reverse sweep driven by
+    the library (the Python-scheduled `grad_virtual` below stays as the CPU-testable reference of the same
+    algorithm).  Returns {"expect", "g_amp", "g_det", "g_u", "g_psi0" (2^N,)} as numpy / torch like grad_virtual."""
+    dloc = 1 << prob.n_local
+    out = _native_value_and_grad(prob, psi0.reshape(prob.world, dloc), tsave, 0, obs_diag.reshape(prob.world, dloc), grad_expect, None, None)
+    return {"expect": out["expect"], "g_amp": out["g_amp"].cpu().numpy(), "g_det": out["g_det"].cpu().numpy(),
+            "g_u": out["g_u"].cpu().numpy(), "g_psi0": out["g_psi0"].reshape(-1), "stats": out["stats"]}
+
+
+def grad_distributed_native(prob: ShardedProblem, psi0_local: Tensor, tsave, obs_diag_local: Tensor, grad_expect, group=None) -> dict:
+    """One process per GPU: every rank runs the native forward + reverse sweep on its slab; state AND cotangent slabs travel through
+    the hypercube exchange callback; the (tiny) expectation values and gradient arrays are all-reduced ONCE at the end."""
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if world != prob.world:
+        raise ValueError(f"world size {world} != 2^{prob.n_gpu_bits}")
+    recv, exchange, lookup, state = _hypercube_exchange(prob, psi0_local, rank, group)
+    try:
+        out = _native_value_and_grad(prob, psi0_local.reshape(1, -1), tsave, rank, obs_diag_local.reshape(1, -1), grad_expect,
+                                     recv, exchange, lookup)
+    except RuntimeError:
+        if state["error"] is not None:
+            raise state["error"]
+        raise
+    flat = torch.cat([out["expect"].reshape(-1), torch.view_as_real(out["g_amp"].contiguous()).reshape(-1), out["g_det"].reshape(-1),
+                      out["g_u"].reshape(-1)])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    n_e, n_a, n_d = out["expect"].numel(), 2 * out["g_amp"].numel(), out["g_det"].numel()
+    return {"expect": flat[:n_e], "g_amp": torch.view_as_complex(flat[n_e:n_e + n_a].clone().reshape(*out["g_amp"].shape, 2)).cpu().numpy(),
+            "g_det": flat[n_e + n_a:n_e + n_a + n_d].reshape(out["g_det"].shape).cpu().numpy(),
+            "g_u": flat[n_e + n_a + n_d:].cpu().numpy(), "g_psi0": out["g_psi0"].reshape(-1), "stats": out["stats"]}
+
+
 class _VirtualFabric:
     """All ranks in this process: a partner's slab is just another list entry."""
 

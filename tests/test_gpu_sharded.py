@@ -72,6 +72,70 @@ def test_virtual_sharded_gradients_match_single_gpu_adjoint(cuda_device, n_qubit
     assert rel_err(out["g_u"], u.grad.cpu().numpy()) < 1e-9
 
 
+@pytest.mark.parametrize("n_qubits,g,variant,tape", [(6, 1, 0, 1), (11, 2, 0, 1), (13, 3, 0, 1), (15, 2, 0, 1), (16, 3, 0, 1), (16, 3, 2, 1), (17, 1, 0, 1),
+                                                     (16, 2, 1, 1)])
+def test_native_sharded_gradients_match_single_gpu_adjoint(cuda_device, n_qubits, g, variant, tape):
+    """K6 completed: the REVERSE sweep of a state-sharded run driven by the library — rydiff_forward with the
+    slabs' trajectory on the workspace tape, then rydiff_backward: cotangent slabs through the same partner reads as the state
+    slabs, the drive gradients of the rank qubits contracted with the partner slabs in the completing launch, per-slab weight
+    tables for dL/dU_ij — against the single-GPU adjoint of the un-sharded problem.  Slabs of 5 .. 16 qubits: direct kernels
+    (<= 12 slab qubits) and chained tiles (1024 / 512 threads), complex tables (phases)."""
+    from pulser_diff_amd import _native
+    from pulser_diff_amd.sharded import grad_virtual_native
+    from pulser_diff_amd.solver import SolverType, evolve
+
+    terms, prob = _problem(n_qubits, g, seed=60 + n_qubits)
+    tsave = torch.linspace(0, 0.02, 5, dtype=torch.float64)
+    psi0 = R.all_ground_state(n_qubits)
+    zd = R.total_magnetization_diag(n_qubits).to(cuda_device)
+    w = torch.linspace(-0.3, 1.2, len(tsave), dtype=torch.float64)
+    amp, det, u, spec = to_native(terms, cuda_device, SolverType.KRYLOV_SE)
+    for t in (amp, det, u):
+        t.requires_grad_(True)
+    _, expect = evolve(amp, det, u, tsave, psi0.T.contiguous().to(cuda_device), spec, zd[None])
+    (expect[0, :, 0] * w.to(cuda_device)).sum().backward()
+    _native.set_kernel_variant(variant)
+    try:
+        out = grad_virtual_native(prob, psi0[:, 0].to(cuda_device), tsave.numpy(), zd, w.numpy())
+    finally:
+        _native.set_kernel_variant(0)
+    assert out["stats"]["kernel_family"] == ("chained-tiles" if (n_qubits - g > 12 and variant != 1) else "direct")
+    assert np.abs(out["expect"].cpu().numpy() - expect[0, :, 0].detach().cpu().numpy()).max() < 1e-10
+    assert rel_err(out["g_amp"], amp.grad[0].cpu().numpy()) < 1e-9
+    assert rel_err(out["g_det"], det.grad[0].cpu().numpy()) < 1e-9
+    assert rel_err(out["g_u"], u.grad.cpu().numpy()) < 1e-9
+
+
+def test_native_sharded_gradients_of_a_phase_free_global_drive(cuda_device):
+    """The same through the single-tape-read adjoint instantiation (one global drive without phase: the drive gradient is RECOVERED
+    from the completed cotangent, which then already contains the partner slabs' part) — the shape of BASELINE config 5."""
+    from pulser_diff_amd.sharded import grad_virtual_native
+    from pulser_diff_amd.solver import SolverType, evolve
+
+    n_qubits, g = 16, 3
+    terms = random_terms(n_qubits, 17, 0.002, seed=777, local=False, phase=False)
+    from pulser_diff_amd.sharded import ShardedProblem
+
+    all_mask = (1 << n_qubits) - 1
+    prob = ShardedProblem(n_qubits, g, terms.dt, terms.amp_coeff.numpy()[None], terms.det_coeff.numpy()[None], [all_mask], [all_mask],
+                          terms.u_pairs.numpy(), tol=1e-13)
+    tsave = torch.linspace(0, 0.03, 6, dtype=torch.float64)
+    psi0 = R.all_ground_state(n_qubits)
+    zd = R.total_magnetization_diag(n_qubits).to(cuda_device)
+    w = torch.linspace(0.4, -0.9, len(tsave), dtype=torch.float64)
+    amp, det, u, spec = to_native(terms, cuda_device, SolverType.KRYLOV_SE)
+    for t in (amp, det, u):
+        t.requires_grad_(True)
+    _, expect = evolve(amp, det, u, tsave, psi0.T.contiguous().to(cuda_device), spec, zd[None])
+    (expect[0, :, 0] * w.to(cuda_device)).sum().backward()
+    out = grad_virtual_native(prob, psi0[:, 0].to(cuda_device), tsave.numpy(), zd, w.numpy())
+    assert out["stats"]["kernel_family"] == "chained-tiles"
+    assert np.abs(out["expect"].cpu().numpy() - expect[0, :, 0].detach().cpu().numpy()).max() < 1e-10
+    assert rel_err(out["g_amp"].real, amp.grad[0].real.cpu().numpy()) < 1e-9
+    assert rel_err(out["g_det"], det.grad[0].cpu().numpy()) < 1e-9
+    assert rel_err(out["g_u"], u.grad.cpu().numpy()) < 1e-9
+
+
 @pytest.mark.parametrize("n_qubits,g,variant", [(5, 1, 0), (8, 3, 0), (12, 2, 0), (14, 1, 0), (15, 2, 0), (16, 3, 0), (17, 3, 4), (16, 2, 1),
                                                 (24, 3, 0)])  # the last one: BASELINE config 5's own shape (8 slabs of 2^21)
 def test_native_sharded_run_matches_single_gpu_solver(cuda_device, n_qubits, g, variant):
@@ -164,6 +228,79 @@ def test_native_sharded_run_over_processes(cuda_device, n_qubits, g):
     for r in results:  # every rank holds the all-reduced expectation values
         assert np.abs(r[2] - expect[0, :, 0].cpu().numpy()).max() < 1e-10
         assert r[3] == ("chained-tiles" if n_qubits - g > 12 else "direct")
+
+
+def _grad_worker(rank, world, port, n_qubits, g, seed, out_q, backend="gloo"):
+    import datetime
+    import os
+
+    import torch.distributed as dist
+
+    from pulser_diff_amd.sharded import grad_distributed_native
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if backend == "nccl":
+        dev = torch.device("cuda", rank)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=120))
+    else:
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        terms, prob = _problem(n_qubits, g, seed=seed)
+        tsave = np.linspace(0, 0.02, 5)
+        psi0 = R.all_ground_state(n_qubits)[:, 0]
+        dloc = 2 ** (n_qubits - g)
+        zd = R.total_magnetization_diag(n_qubits)
+        w = np.linspace(-0.3, 1.2, len(tsave))
+        out = grad_distributed_native(prob, psi0[rank * dloc:(rank + 1) * dloc].to(dev), tsave, zd[rank * dloc:(rank + 1) * dloc].to(dev), w)
+        out_q.put((rank, out["expect"].cpu().numpy(), out["g_amp"], out["g_det"], out["g_u"], out["g_psi0"].cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_qubits,g", [(9, 1), (15, 2)])
+def test_native_sharded_gradients_over_processes(cuda_device, n_qubits, g):
+    """The native reverse sweep with the ranks in SEPARATE processes (one slab each, all on the one GPU, gloo as transport): state
+    and cotangent slabs go through the exchange callback, the gradient arrays are all-reduced once; every rank must end with the
+    single-GPU adjoint's gradients and its own slab of dL/dpsi0."""
+    import socket
+
+    import torch.multiprocessing as mp
+    from pulser_diff_amd.solver import SolverType, evolve
+
+    world = 2**g
+    with socket.socket() as sck:
+        sck.bind(("127.0.0.1", 0))
+        port = sck.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, n_qubits, g, 800 + n_qubits, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    try:
+        results = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    finally:
+        for p_ in procs:
+            p_.join(timeout=60)
+            if p_.is_alive():
+                p_.kill()
+    assert all(p_.exitcode == 0 for p_ in procs)
+    terms, prob = _problem(n_qubits, g, seed=800 + n_qubits)
+    psi0 = R.all_ground_state(n_qubits).T.contiguous().to(cuda_device).requires_grad_(True)
+    zd = R.total_magnetization_diag(n_qubits).to(cuda_device)
+    w = torch.linspace(-0.3, 1.2, 5, dtype=torch.float64, device=cuda_device)
+    amp, det, u, spec = to_native(terms, cuda_device, SolverType.KRYLOV_SE)
+    for t in (amp, det, u):
+        t.requires_grad_(True)
+    _, expect = evolve(amp, det, u, torch.linspace(0, 0.02, 5, dtype=torch.float64), psi0, spec, zd[None])
+    (expect[0, :, 0] * w).sum().backward()
+    for r in results:
+        assert np.abs(r[1] - expect[0, :, 0].detach().cpu().numpy()).max() < 1e-10
+        assert rel_err(r[2], amp.grad[0].cpu().numpy()) < 1e-9
+        assert rel_err(r[3], det.grad[0].cpu().numpy()) < 1e-9
+        assert rel_err(r[4], u.grad.cpu().numpy()) < 1e-9
+    assert rel_err(np.concatenate([r[5] for r in results]), psi0.grad[0].cpu().numpy()) < 1e-9
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL path needs one GPU per rank (runs on the driver's multi-GPU box)")
