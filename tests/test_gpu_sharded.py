@@ -304,6 +304,46 @@ def test_native_sharded_gradients_over_processes(cuda_device, n_qubits, g):
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL path needs one GPU per rank (runs on the driver's multi-GPU box)")
+def test_native_sharded_gradients_over_rccl(cuda_device):
+    """RCCL twin of test_native_sharded_gradients_over_processes: one GPU per rank, state and cotangent slabs over xGMI.  Skipped on
+    this pool's one-GPU boxes; bounded by the ranks' 120 s collective timeout and the 240 s queue timeout."""
+    import socket
+
+    import torch.multiprocessing as mp
+    from pulser_diff_amd.solver import SolverType, evolve
+
+    n_qubits, g, world = 15, 1, 2
+    with socket.socket() as sck:
+        sck.bind(("127.0.0.1", 0))
+        port = sck.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, n_qubits, g, 950, q, "nccl")) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    try:
+        results = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    finally:
+        for p_ in procs:
+            p_.join(timeout=30)
+            if p_.is_alive():
+                p_.kill()
+    assert all(p_.exitcode == 0 for p_ in procs)
+    terms, prob = _problem(n_qubits, g, seed=950)
+    psi0 = R.all_ground_state(n_qubits).T.contiguous().to(cuda_device)
+    zd = R.total_magnetization_diag(n_qubits).to(cuda_device)
+    w = torch.linspace(-0.3, 1.2, 5, dtype=torch.float64, device=cuda_device)
+    amp, det, u, spec = to_native(terms, cuda_device, SolverType.KRYLOV_SE)
+    for t in (amp, det, u):
+        t.requires_grad_(True)
+    _, expect = evolve(amp, det, u, torch.linspace(0, 0.02, 5, dtype=torch.float64), psi0, spec, zd[None])
+    (expect[0, :, 0] * w).sum().backward()
+    for r in results:
+        assert rel_err(r[2], amp.grad[0].cpu().numpy()) < 1e-9 and rel_err(r[3], det.grad[0].cpu().numpy()) < 1e-9
+        assert rel_err(r[4], u.grad.cpu().numpy()) < 1e-9
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL path needs one GPU per rank (runs on the driver's multi-GPU box)")
 @pytest.mark.parametrize("n_qubits,g", [(15, 1), (16, 2)])
 def test_native_sharded_run_over_rccl(cuda_device, n_qubits, g):
     """run_distributed_native with the NCCL (= RCCL) backend, one GPU per rank: the branch that posts the hypercube
