@@ -33,9 +33,10 @@ def test_ka1_default_solver_reproduces_notebook_series_and_continuous_solution(c
     res = sim.run()
     ez = res.expect([total_magnetization(4)])[0].real.cpu().numpy()
     assert np.abs(ez - np.array(PINS["ka1_sum_z"])).max() < 1e-4
-    ham = sim._hamiltonian
-    terms = R.HamTerms(4, ham._u_pairs_host, ham._amp_terms[0][0], ham._det_terms[0][0], ham.dt, ham.n_samples,
-                       [0, 1, 2, 3], [0, 1, 2, 3])
+    # the oracle's problem from the notebook's DEFINITIONS (oracle waveforms, register coordinates), not from the product's tables
+    oseq = R.concat_pulses([(R.blackman_waveform(800, f32pi), R.ramp_waveform(800, torch.tensor(-5.0), 0.0), 0.0),
+                            (R.constant_waveform(800, torch.tensor(5.0)), R.constant_waveform(800, 0.0), 0.0)])
+    terms = R.build_terms(oseq, torch.tensor([[0, 0], [0, 8], [8, 0], [8, 8]], dtype=torch.float64), 0.1)
     cont = R.continuous_solution(terms, R.all_ground_state(4).numpy(), sim.evaluation_times.numpy())
     assert np.abs(res.states.cpu().numpy() - cont).max() < 1e-8
 

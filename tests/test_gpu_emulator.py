@@ -132,12 +132,14 @@ def test_local_channel_sequence_and_batched_initial_states(cuda_device):
     sim.set_initial_state(torch.eye(8, dtype=torch.complex128))  # gate-optimisation style: (dim, B=dim)
     res = sim.run(solver=SolverType.KRYLOV_SE)
     states = res.states.cpu()  # (n_t, dim, B)
-    # oracle with the same tables
-    ham = sim._hamiltonian
-    terms = R.HamTerms(3, ham._u_pairs_host, ham._amp_terms[0][0], ham._det_terms[0][0], ham.dt, ham.n_samples,
-                       [0, 1, 2], [0, 1, 2])
-    terms.extra_amp = [(ham._amp_terms[1][0], [1])]
-    terms.extra_det = [(ham._det_terms[1][0], [1])]
+    # oracle from the pulses' definitions: the global channel (120 ns) and, in parallel from t = 0, the local channel on q1 (80 ns)
+    coords = torch.stack([reg.qubits[q] for q in reg.qubit_ids])
+    z40 = torch.zeros(40, dtype=torch.float64)
+    terms = R.build_terms(R.concat_pulses([(R.constant_waveform(120, 4.0), R.constant_waveform(120, 1.0), 0.2)]), coords, 1.0)
+    lamp = torch.cat([R.ramp_waveform(80, 0.0, 6.0), z40, torch.zeros(1, dtype=torch.float64)])
+    ldet = torch.cat([R.constant_waveform(80, -2.0), z40, torch.zeros(1, dtype=torch.float64)])
+    terms.extra_amp = [(0.5 * lamp * torch.exp(-1j * torch.full((121,), 0.5, dtype=torch.complex128)), [1])]
+    terms.extra_det = [(-0.5 * ldet, [1])]
     ref = R.krylov_map_dense(terms, torch.eye(8, dtype=torch.complex128), sim.evaluation_times)
     assert (states - ref).abs().max() < 1e-10
     # the propagator of a unitary evolution is unitary

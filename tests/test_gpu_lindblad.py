@@ -131,9 +131,9 @@ def test_emulator_runs_the_master_equation_and_returns_density_results(cuda_devi
     z_clean = clean.expect([total_magnetization(n)])[0].real.cpu().numpy()
     assert z_dense[0] == -n and np.abs(z_dense - z_clean).max() > 1e-2  # decoherence changes the dynamics
     # against the oracle's dense solution of the same sequence
-    ham = sim._hamiltonian
-    terms = R.HamTerms(n, ham._u_pairs_host, ham._amp_terms[0][0], ham._det_terms[0][0], ham.dt, ham.n_samples,
-                       list(range(n)), list(range(n)))
+    # (the oracle's terms from the pulse's DEFINITION and the register's coordinates, not from the product's tables)
+    coords = torch.stack([sim._register.qubits[q] for q in sim._register.qubit_ids])
+    terms = R.build_terms(R.concat_pulses([(R.blackman_waveform(300, 2.4), R.ramp_waveform(300, -3.0, 2.0), 0.2)]), coords, 1.0)
     psi0 = R.all_ground_state(n)[:, 0]
     ref = R.lindblad_continuous_solution(terms, R.collapse_operators(n, {"relaxation": 0.5, "dephasing": 1.0}),
                                          torch.outer(psi0, psi0.conj()).numpy(), sim.evaluation_times.numpy())
@@ -200,9 +200,9 @@ def test_digital_basis_dephasing_uses_the_hyperfine_rate_and_refuses_relaxation(
     sim.set_config(P.SimConfig(noise="dephasing", dephasing_rate=5.0, hyperfine_dephasing_rate=0.8))
     res = sim.run()  # collapse operators force the master equation (backend.py:482-488)
     rho = res.states[..., 0].cpu().numpy()
-    ham = sim._hamiltonian
-    terms = R.HamTerms(2, torch.zeros(1, dtype=torch.float64), ham.amp_tables[0, 0].cpu(), ham.det_tables[0, 0].cpu(), ham.dt, ham.n_samples,
-                       [0, 1], [0, 1])  # digital basis: same drive structure, no interaction term (hamiltonian.py:460)
+    # digital basis: same drive structure, no interaction term (hamiltonian.py:460); terms from the pulse's definition
+    terms = R.build_terms(R.concat_pulses([(R.blackman_waveform(120, 2.4), R.ramp_waveform(120, -3.0, 2.0), 0.3)]),
+                          torch.tensor([[0.0, 0.0], [7.0, 0.0]], dtype=torch.float64), 0.5, u_pairs=torch.zeros(1, dtype=torch.float64))
     psi0 = sim.initial_state[:, 0]
     ts = sim.evaluation_times.detach().cpu().numpy()
     ref = R.lindblad_continuous_solution(terms, R.collapse_operators(2, {"dephasing": 0.8}), torch.outer(psi0, psi0.conj()).numpy(), ts)
