@@ -12,6 +12,10 @@ outputs, so the GPU tests (tests/test_gpu_baseline_fixtures.py) feed the native 
   baseline_c3_full  C3 at FULL length (round 3): all 1000 steps of bench.py's first parameter set on the 20-qubit 4x5 register in ONE
                     checkpointed autograd run of the matrix-free map: <sum Z>(t_k) at all 1001 save points, |psi_T|, 16 amplitudes
                     at T/2 and T, and the 8 parameter gradients of <sum Z>(T) through all 1000 steps (about 1.5 h on 8 cores)
+  baseline_c4_full  C4's template at FULL length (round 3): bench.py's first two parameter sets on the 16-qubit 4x4 register, all 1000
+                    steps each, checkpointed autograd: <sum Z>(t_k) at 1001 points, 16 amplitudes at T, the 8 gradients of <sum Z>(T)
+  baseline_c5       BASELINE config 5 (round 3): 24-qubit 4x6 register, Blackman(100 ns, 2 pi) + Ramp(-5 -> +5), 100 steps, forward:
+                    <sum Z>(t_k) at 101 points, |psi_T|, 16 amplitudes at T/2 and T (about 40 min on 8 cores)
   baseline_c3_grad  20-qubit 4x5, the same parameter set on a compressed pulse (4 segments x 3 ns): the 8 parameter gradients of
                     <sum Z>(T) by autograd through the oracle's matrix-free map
   grad_dense_n8/n10 all five gradient kinds (amplitude tables Re/Im, detuning tables, U_ij, tsave, psi0) by autograd through the
@@ -172,6 +176,57 @@ def make_c3_full(steps=1000, name="baseline_c3_full"):
                         g_omega=omega.grad.numpy(), g_delta=delta.grad.numpy())
 
 
+def make_c4_full(steps=1000):
+    """C4's own length: 4 segments x 250 ns on 16 qubits, bench.py's parameter sets 0 and 1."""
+    n, seg_len = 16, 250
+    omega0, delta0 = bench_parameter_sets(256)
+    coords = grid_coords(4, 4)
+    zd = R.total_magnetization_diag(n)
+    idx = AMP_IDX(2**n)
+    z_all, amps, g_om, g_de = [], [], [], []
+    for b in range(2):
+        omega = omega0[b].clone().requires_grad_(True)
+        delta = delta0[b].clone().requires_grad_(True)
+        seq = segment_sequence(omega, delta, seg_len)
+        terms = R.build_terms(seq, coords, 1.0)
+        tsave = R.evaluation_times(seq.tot_duration, 1.0)[: steps + 1]
+        z_t = []
+        psi = R.krylov_map_matrix_free_torch(terms, R.all_ground_state(n)[:, 0], tsave, checkpoint=True,
+                                             on_state=lambda k, st: z_t.append(float(((st.detach().abs() ** 2) * zd).sum())))
+        ((psi.abs() ** 2) * zd).sum().backward()
+        z_all.append(np.array(z_t))
+        amps.append(psi.detach().numpy()[idx])
+        g_om.append(omega.grad.numpy())
+        g_de.append(delta.grad.numpy())
+    np.savez_compressed(OUT / "baseline_c4_full.npz", omega=omega0[:2].numpy(), delta=delta0[:2].numpy(), seg_len=seg_len, coords=coords.numpy(),
+                        tsave=tsave.numpy(), z_t=np.stack(z_all), amp_idx=idx, amps_T=np.stack(amps), g_omega=np.stack(g_om), g_delta=np.stack(g_de))
+
+
+def make_c5(steps=100):
+    """BASELINE config 5 as bench.py runs it (register_coords("c5") = 4x6 grid, blackman_ramp_tables(100, 2 pi, -5, +5)), forward."""
+    n, T = 24, 100
+    seq = R.concat_pulses([(R.blackman_waveform(T, 2 * np.pi), R.ramp_waveform(T, -5.0, 5.0), 0.0)])
+    coords = grid_coords(4, 6)
+    terms = R.build_terms(seq, coords, 1.0)
+    tsave = R.evaluation_times(seq.tot_duration, 1.0)[: steps + 1]
+    zd = R.total_magnetization_diag(n)
+    idx = AMP_IDX(2**n)
+    z_t, mid = [], []
+    t0 = time.time()
+
+    def on_state(k, st):
+        z_t.append(float(((st.abs() ** 2) * zd).sum()))
+        if k == steps // 2:
+            mid.append(st.numpy()[idx].copy())
+        if k % 10 == 0:
+            print(f"   step {k}: <sum Z> = {z_t[-1]:+.12f}   {time.time() - t0:.0f} s", flush=True)
+
+    with torch.no_grad():
+        psi = R.krylov_map_matrix_free_torch(terms, R.all_ground_state(n)[:, 0], tsave, on_state=on_state)
+    np.savez_compressed(OUT / "baseline_c5.npz", amp=seq.amp.numpy(), det=seq.det.numpy(), coords=coords.numpy(), tsave=tsave.numpy(),
+                        z_t=np.array(z_t), norm_T=float(torch.linalg.vector_norm(psi)), amp_idx=idx, amps_T=psi.numpy()[idx], amps_mid=mid[0])
+
+
 def leaf_terms(terms):
     o = R.HamTerms(terms.n_qubits, terms.u_pairs.clone().requires_grad_(True), terms.amp_coeff.clone().requires_grad_(True),
                    terms.det_coeff.clone().requires_grad_(True), terms.dt, terms.n_samples, terms.amp_targets, terms.det_targets)
@@ -242,6 +297,8 @@ MAKERS = {
     "baseline_c3": make_c3,
     "baseline_c3_grad": make_c3_grad,
     "baseline_c3_full": make_c3_full,
+    "baseline_c4_full": make_c4_full,
+    "baseline_c5": make_c5,
     "grad_dense_n8": lambda: gradient_fixture("grad_dense_n8", 8, 808, R.krylov_map_dense),
     "grad_dense_n10": lambda: gradient_fixture("grad_dense_n10", 10, 1010, R.krylov_map_dense),
     "grad_mf_n14": lambda: gradient_fixture("grad_mf_n14", 14, 1414, lambda o, p, t: R.krylov_map_matrix_free_torch(o, p, t), fd_check=True),
@@ -250,7 +307,7 @@ MAKERS = {
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    for name in (sys.argv[1:] or [m for m in MAKERS if m != "baseline_c3_full"]):  # the full-length run only when named
+    for name in (sys.argv[1:] or [m for m in MAKERS if m not in ("baseline_c3_full", "baseline_c4_full", "baseline_c5")]):  # the long runs only when named
         t0 = time.time()
         MAKERS[name]()
         print(f"{name}: {time.time() - t0:.1f} s, {(OUT / (name + '.npz')).stat().st_size / 1024:.1f} KiB", flush=True)
