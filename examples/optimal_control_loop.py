@@ -6,6 +6,9 @@ import torch
 
 
 def train(model, loss_of, epochs, lr, t_max=50, stop_below=1e-4, plateau_window=6, plateau_change=0.01, clamp=False, log_every=50):
+    from pulser_diff_amd.utils import freeze_gc
+
+    freeze_gc()  # an epoch takes milliseconds here: keep CPython's generation-2 passes (~35 ms over torch's object graph) out of the loop
     opt = torch.optim.Adam(model.parameters(), lr=lr)
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=t_max)
     history, best = [], (float("inf"), None, -1)

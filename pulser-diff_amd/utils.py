@@ -148,3 +148,17 @@ def interpolate_sine(num_values: int, duration: int) -> Tensor:
         if idx < num_values:
             mat[k, idx] = s(h)
     return mat
+
+
+def freeze_gc() -> None:
+    """Move every object that is alive NOW (torch's ~1e5 module-level objects, the built model) into the garbage collector's
+    permanent generation (``gc.freeze()``), after one full collection.  A training loop on a small register runs an epoch in a
+    few milliseconds; a generation-2 pass of CPython's collector over torch's object graph takes ~35 ms and comes every few
+    dozen epochs — on the 9-qubit timing of round 2 exactly such a pause looked like a 1.8 x slower kernel
+    (profiles/r03_small_register_tape_walk.txt).  Call once after the model is built; nothing is leaked (frozen objects stay
+    referenced as before, they are only no longer traversed), and ``gc.unfreeze()`` undoes it."""
+    import gc
+
+    gc.collect()
+    gc.freeze()
+

@@ -4,6 +4,8 @@ import sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch
+import gc
+gc.collect(); gc.freeze()  # torch's ~1e5 long-lived objects out of the collector's way: a gen-2 pass costs ~35 ms (profiles/r03_small_register_tape_walk.txt)
 from pulser_diff_amd.solver import ProblemSpec, SolverType, evolve
 
 n_min = int(sys.argv[1]) if len(sys.argv) > 1 else 1
