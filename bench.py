@@ -735,6 +735,20 @@ def cpu_baseline(workload, n_qubits, coords, T, seg_len, omega, delta, fixed_tab
                "sample": f"time steps {k0}..{k0 + n_steps} (middle of the trajectory, state spread over the basis) of the {T} steps of "
                          f"the same {n_qubits}-qubit workload, forward only: sparse-COO H(t) rebuild + Krylov exp per step "
                          f"(oracle/restatement.py) on the best of the probed thread counts ({best}); {dt:.1f} s"}
+        # a third line, the fairest to the CPU: the oracle's matrix-free map in torch (Taylor series of the exponential, no sparse
+        # matrix at all), on the thread count that is best for dense elementwise work (all physical cores up to 64) — what a CPU
+        # implementation of THIS repository's algorithmic idea would do; also the only matrix-free line that still runs at 20 qubits
+        try:
+            mf_threads = min(cores, 64)
+            torch.set_num_threads(mf_threads)
+            R.krylov_map_matrix_free_torch(terms, psi_mid, ts[:2])  # warm (tables, thread pool)
+            t2 = time.perf_counter()
+            R.krylov_map_matrix_free_torch(terms, psi_mid, ts)
+            dt_t = time.perf_counter() - t2
+            res["matrix_free_torch"] = {"value": n_steps / dt_t, "unit": "time-steps/s", "cores": mf_threads,
+                                        "sample": f"the same {n_steps} step(s), the oracle's matrix-free Taylor map (torch CPU, fp64); {dt_t:.1f} s"}
+        finally:
+            torch.set_num_threads(best)
         if n_qubits <= 16:
             # second, fairer CPU line: the oracle's own MATRIX-FREE Krylov map (numpy, one core), no sparse H
             # (dropped at 20 qubits, where one step takes over a minute)
