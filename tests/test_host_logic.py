@@ -564,3 +564,16 @@ def test_refreshed_emulator_gets_a_fresh_time_leaf_and_compares_measurement_and_
     assert sim._eval_times_array is not leaf and not sim._eval_times_array.requires_grad
     assert torch.equal(sim._eval_times_array, leaf.detach())
     assert not sim.refresh_from_sequence(seq_for((0.0, 0.0, 1.0)))   # another field: another interaction
+
+
+def test_freeze_gc_moves_live_objects_out_of_the_collectors_way():
+    import gc
+
+    from pulser_diff_amd.utils import freeze_gc
+
+    before = gc.get_freeze_count()
+    try:
+        freeze_gc()
+        assert gc.get_freeze_count() > before
+    finally:
+        gc.unfreeze()
