@@ -17,11 +17,8 @@
 // read consecutive 16-byte slots of a permuted 1 KiB span).
 #pragma once
 
-#ifndef RYDIFF_TILE_BITS
-#define RYDIFF_TILE_BITS 12
-#endif
-constexpr int kTileBits = RYDIFF_TILE_BITS;
-constexpr unsigned kTileAmps = 1u << kTileBits;
+constexpr int kTileBits = 12;      // k_chain: 2^12 amplitudes per workgroup (64 KiB of LDS)
+constexpr int kWideTileBits = 13;  // k_chain_wide: 2^13 amplitudes per workgroup (128 KiB of the 160 KiB LDS), 21-24 qubits
 
 // Streaming store: the vectors written by a pass are read next by OTHER workgroups in the other tile layout, never by
 // this one, so there is no point keeping the lines dirty in this XCD's L2 until the end-of-kernel write-back.
@@ -683,4 +680,374 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
     __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): the stores of this wave have been acknowledged
     RYDIFF_TL(7);
 #endif
+}
+
+// ---- wide tiles: 2^(LGT+3) amplitudes per 1024-thread workgroup, processed in two register halves --------------------------
+// Same launch contract as k_chain (ChainArgs; forward and adjoint passes).  A tile of 2^13 amplitudes (128 KiB of the 160 KiB LDS)
+// gives the second tile layout runs of 512 / 256 / 128 / 64 bytes at 21 / 22 / 23 / 24 qubits where 2^12-amplitude tiles have
+// 128 / 64 / 32 / 16 — so two layouts (2R+2W per factor) reach 24 qubits.  k_chain instantiated with 8 amplitudes per thread keeps
+// u, the accumulator, both partner sums and the output of ALL eight in registers and spills (48-328 VGPRs:
+// profiles/r03_tile_size_and_line_sharing.txt).  Here only the accumulator (the vector the finish stage completes) stays in
+// registers for all eight; u lives in LDS only (own element re-read where the adjoint needs it), and partner sums, tape values,
+// diagonal and output exist for FOUR amplitudes at a time.  In the finish stage every partner comes from LDS, in the start stage
+// the three register bits are register renaming as in k_chain.  No trajectory-per-XCD placement (registers of this size are never
+// L2-resident).  The arithmetic per amplitude is that of k_chain, statement by statement.
+template <int LT, bool CPLX, bool BWD, bool FAST>
+__global__ __launch_bounds__(1024) void k_chain_wide(ChainArgs a) {
+    constexpr int LGT = 10, NT = 1 << LGT, R = 1 << (LT - LGT), RH = R / 2, NW = NT / 64;
+    static_assert(R == 8, "two halves of four amplitudes per thread");
+    constexpr bool REC = BWD && FAST && !CPLX;
+    const int GA = FAST ? 1 : a.ga;
+    const int GD = FAST ? (a.gd ? 1 : 0) : a.gd;
+    extern __shared__ __attribute__((aligned(16))) double2 tile[];
+    double* red = reinterpret_cast<double*>(tile + (size_t(1) << LT));
+    const int n_slots = BWD ? 4 * a.ga + a.gd : 0;
+    if (BWD) {
+        for (int s = int(threadIdx.x); s < n_slots * NW; s += NT) red[s] = 0.0;  // published by the barrier after the tile write
+    }
+    const unsigned tid = threadIdx.x;
+    unsigned t = blockIdx.x;
+    if (a.tile_swz) {
+        const unsigned w = blockIdx.x, G = 1u << a.tile_swz;
+        t = (w & ~(8u * G - 1u)) | ((w & 7u) << a.tile_swz) | ((w >> 3) & (G - 1u));
+    }
+    const unsigned bl = blockIdx.y;
+    const unsigned bt = unsigned(a.b_first) + bl;
+    const size_t boff = size_t(bt) * a.dim;
+    const unsigned rank = unsigned(a.sh_rank_first) + bl;
+    const unsigned rank_hi = a.sh_bits ? (rank << a.sh_nl) : 0u;
+    const unsigned t_glob = a.sh_bits ? (t + (rank << (a.sh_nl - LT))) : t;
+    const unsigned lomask = (1u << a.lo) - 1u;
+    const int midlow = a.hs - a.lo;
+    const unsigned xbase = ((t & ((1u << midlow) - 1u)) << a.lo) | ((t >> midlow) << (a.hs + a.hb));
+    auto xg_of = [&](int r) -> unsigned {
+        const unsigned i = unsigned(r) * NT + tid;
+        return xbase | (i & lomask) | ((i >> a.lo) << a.hs);
+    };
+    double* ge_fin = nullptr;
+    double* ge_sta = nullptr;
+    if (BWD) {
+        const long goff = bt * a.ge_bstride + (blockIdx.x % kGradReplicas) * a.ge_rstride;
+        ge_fin = a.ge_fin + goff;
+        ge_sta = a.ge_sta + goff;
+    }
+    auto flush_gradients = [&]() {
+        __syncthreads();
+        for (int s = int(threadIdx.x); s < n_slots; s += NT) {
+            double sum = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sum += red[s * NW + w];
+            double* dst;
+            if (s < 2 * a.ga) dst = ge_fin + ((s & 1) ? a.ga : 0) + (s >> 1);
+            else if (s < 2 * a.ga + a.gd) dst = (REC ? ge_fin : ge_sta) + 2 * a.ga + (s - 2 * a.ga);
+            else dst = ge_sta + (((s - 2 * a.ga - a.gd) & 1) ? a.ga : 0) + ((s - 2 * a.ga - a.gd) >> 1);
+            if (sum != 0.0) unsafeAtomicAdd(dst, sum);
+        }
+    };
+    // interaction diagonal of amplitude (rf, tid): tile-local table + remote part of this tile + cross terms of the tile bits in |r>
+    const double* __restrict__ vrow = a.vr + size_t(t_glob) * 16;
+    auto lane_diag = [&]() -> double {  // (computed where it is used: two registers less across the finish stage)
+        double dlane = vrow[LT];
+#pragma unroll
+        for (int b2 = 0; b2 < LGT; ++b2)
+            if (!(tid >> b2 & 1u)) dlane += vrow[b2];
+        return dlane;
+    };
+    auto diag_of = [&](int rf, double dlane) -> double {
+        double d = a.utt[unsigned(rf) * NT + tid] + dlane;
+#pragma unroll
+        for (int b2 = LGT; b2 < LT; ++b2)
+            if (!(rf >> (b2 - LGT) & 1)) d += vrow[b2];
+        return d;
+    };
+    bool exact_fin = true, exact_sta = true;
+    if constexpr (REC) {
+        exact_fin = !(fabs(a.coef_fin[bt * a.coef_bstride]) * sqrt(a.fb_r * a.fb_r + a.fb_i * a.fb_i) >= kRecMinBetaC);
+        exact_sta = !(fabs(a.coef_sta[bt * a.coef_bstride]) * sqrt(a.sb_r * a.sb_r + a.sb_i * a.sb_i) >= kRecMinBetaC);
+    }
+
+    double2 acc[R];
+    {
+        double2 uu[RH];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {  // u goes straight to LDS, four amplitudes at a time
+#pragma unroll
+            for (int r = 0; r < RH; ++r) uu[r] = stream_load(a.u + boff + xg_of(h * RH + r));
+#pragma unroll
+            for (int r = 0; r < RH; ++r) tile[unsigned(h * RH + r) * NT + tid] = uu[r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = stream_load(a.p + boff + xg_of(r));  // (the host passes p = u for a chain's first launch)
+    __syncthreads();
+
+    bool inj_any = false;
+    if (BWD && a.has_p && a.inj_gexp) {
+        for (int o = 0; o < a.inj_n_obs; ++o) inj_any |= a.inj_gexp[o * a.inj_ostride + bt] != 0.0;
+    }
+    auto finish_half = [&](auto hc) {
+        constexpr int h = decltype(hc)::value;
+        const double* __restrict__ cf = a.coef_fin + bt * a.coef_bstride;
+        double2 xf[RH];
+        if (BWD) {
+#pragma unroll
+            for (int r = 0; r < RH; ++r) xf[r] = stream_load(a.x_fin + boff + xg_of(h * RH + r));
+        }
+        if (a.has_p) {
+            for (int g = 0; g < GA; ++g) {
+                const uint32_t mask = a.fin_mask[g];
+                if (!mask) continue;
+                double2 ts[RH], ds[RH];
+#pragma unroll
+                for (int r = 0; r < RH; ++r) {
+                    ts[r] = make_double2(0.0, 0.0);
+                    ds[r] = make_double2(0.0, 0.0);
+                }
+#pragma unroll
+                for (int b = 0; b < LT; ++b) {
+                    if (mask >> b & 1u) {  // wave-uniform
+#pragma unroll
+                        for (int r = 0; r < RH; ++r) {
+                            const unsigned i = unsigned(h * RH + r) * NT + tid;
+                            const double2 q = tile[i ^ (1u << b)];
+                            ts[r].x += q.x;
+                            ts[r].y += q.y;
+                            if (CPLX) {
+                                const double sgn = (i >> b & 1u) ? 1.0 : -1.0;
+                                ds[r].x = fma(sgn, q.x, ds[r].x);
+                                ds[r].y = fma(sgn, q.y, ds[r].y);
+                            }
+                        }
+                    }
+                }
+                const double cr = cf[g], ci = cf[a.ga + g];
+                const double k1r = a.fb_r * cr, k1i = a.fb_i * cr;
+                const double k2r = -a.fb_i * ci, k2i = a.fb_r * ci;
+#pragma unroll
+                for (int r = 0; r < RH; ++r) {
+                    double2& A = acc[h * RH + r];
+                    A.x += k1r * ts[r].x - k1i * ts[r].y;
+                    A.y += k1r * ts[r].y + k1i * ts[r].x;
+                    if (CPLX) {
+                        A.x += k2r * ds[r].x - k2i * ds[r].y;
+                        A.y += k2r * ds[r].y + k2i * ds[r].x;
+                    }
+                }
+                if (BWD && exact_fin) {
+                    double z1r = 0.0, z1i = 0.0, z2r = 0.0, z2i = 0.0;
+#pragma unroll
+                    for (int r = 0; r < RH; ++r) {
+                        z1r += ts[r].x * xf[r].x + ts[r].y * xf[r].y;
+                        z1i += ts[r].x * xf[r].y - ts[r].y * xf[r].x;
+                        if (CPLX) {
+                            z2r += ds[r].x * xf[r].x + ds[r].y * xf[r].y;
+                            z2i += ds[r].x * xf[r].y - ds[r].y * xf[r].x;
+                        }
+                    }
+                    if (CPLX) park2<NW>(a.cb_fin_r * z1r - a.cb_fin_i * z1i, a.cb_fin_r * z2i + a.cb_fin_i * z2r, red, 2 * g, 2 * g + 1);
+                    else park1<NW>(a.cb_fin_r * z1r - a.cb_fin_i * z1i, red, 2 * g);
+                }
+            }
+            if (a.completes && a.sh_bits) {  // rank-qubit flips: the partner slabs' complete vector at the same local index
+                for (int k = 0; k < a.sh_bits; ++k) {
+                    const int g = a.sh_grp[k];
+                    if (g < 0) continue;
+                    const double cr = cf[g], ci = (rank >> k & 1u) ? cf[a.ga + g] : -cf[a.ga + g];  // row g: c, row r: conj c
+                    const double kr = a.fb_r * cr - a.fb_i * ci, ki = a.fb_r * ci + a.fb_i * cr;
+                    const double2* __restrict__ src = a.sh_self ? a.u + size_t(unsigned(a.b_first) + (bl ^ (1u << k))) * a.dim : a.sh_rem[k] + size_t(bl) * a.dim;
+                    const double sgn = (rank >> k & 1u) ? 1.0 : -1.0;
+                    double z1r = 0.0, z1i = 0.0;
+#pragma unroll
+                    for (int r = 0; r < RH; ++r) {
+                        const double2 pv = src[xg_of(h * RH + r)];
+                        acc[h * RH + r].x += kr * pv.x - ki * pv.y;
+                        acc[h * RH + r].y += kr * pv.y + ki * pv.x;
+                        if (BWD) {
+                            z1r += pv.x * xf[r].x + pv.y * xf[r].y;
+                            z1i += pv.x * xf[r].y - pv.y * xf[r].x;
+                        }
+                    }
+                    if (BWD && exact_fin) {
+                        if (CPLX) park2<NW>(a.cb_fin_r * z1r - a.cb_fin_i * z1i, sgn * (a.cb_fin_r * z1i + a.cb_fin_i * z1r), red, 2 * g, 2 * g + 1);
+                        else park1<NW>(a.cb_fin_r * z1r - a.cb_fin_i * z1i, red, 2 * g);
+                    }
+                }
+            }
+            if constexpr (REC) {
+                if (a.completes) {  // acc = mu' (before any injected cotangent), tile = mu, xf = the factor's input
+                    double sgd = 0.0, zr = 0.0;
+                    const double cdet = GD ? cf[2] : 0.0;
+                    const double dlane = exact_fin ? 0.0 : lane_diag();
+#pragma unroll
+                    for (int r = 0; r < RH; ++r) {
+                        const int rf = h * RH + r;
+                        const double2 mu = tile[unsigned(rf) * NT + tid];
+                        const unsigned x = xg_of(rf);
+                        const double pr = a.cb_fin_r * mu.x + a.cb_fin_i * mu.y, pi = a.cb_fin_i * mu.x - a.cb_fin_r * mu.y;
+                        const double w = pr * xf[r].x - pi * xf[r].y;
+                        if (a.wtot) unsafeAtomicAdd(a.wtot + (a.sh_bits ? boff : 0) + x, w);
+                        const double cnt = GD ? double(a.dcnt[0] - popc_i((x | rank_hi) & a.dmask[0])) : 0.0;
+                        sgd += w * cnt;
+                        if (!exact_fin) {  // Re <mu' - (gamma~ + beta~ d) mu, x>
+                            const double d = diag_of(rf, dlane) + cdet * cnt;
+                            const double dr = a.fg_r + a.fb_r * d, di = a.fg_i + a.fb_i * d;
+                            const double wx = acc[rf].x - (dr * mu.x - di * mu.y), wy = acc[rf].y - (dr * mu.y + di * mu.x);
+                            zr += wx * xf[r].x + wy * xf[r].y;
+                        }
+                    }
+                    if (GD) park1<NW>(sgd, red, 2 * a.ga);
+                    if (!exact_fin) park1<NW>(zr / cf[0], red, 0);
+                }
+            }
+        }
+        if (BWD && a.has_p && (a.inj_gexp || a.inj_gstate)) {  // the completed cotangent sits at a save point: fused injection
+            if (inj_any) {
+#pragma unroll
+                for (int r = 0; r < RH; ++r) {
+                    double wsum = 0.0;
+                    for (int o = 0; o < a.inj_n_obs; ++o)
+                        wsum += a.inj_gexp[o * a.inj_ostride + bt] * a.inj_obs[size_t(o) * a.obs_ostride + bt * a.obs_bstride + xg_of(h * RH + r)];
+                    acc[h * RH + r].x += 2.0 * wsum * xf[r].x;
+                    acc[h * RH + r].y += 2.0 * wsum * xf[r].y;
+                }
+            }
+            if (a.inj_gstate) {
+#pragma unroll
+                for (int r = 0; r < RH; ++r) {
+                    const double2 gs = stream_load(a.inj_gstate + boff + xg_of(h * RH + r));
+                    acc[h * RH + r].x += gs.x;
+                    acc[h * RH + r].y += gs.y;
+                }
+            }
+        }
+        if (a.write_v) {
+#pragma unroll
+            for (int r = 0; r < RH; ++r) stream_store(a.v_out + boff + xg_of(h * RH + r), acc[h * RH + r]);
+        }
+    };
+    finish_half(std::integral_constant<int, 0>{});
+    finish_half(std::integral_constant<int, 1>{});
+
+    if (!BWD && a.obs) {  // <v|O|v> for diagonal observables, straight from the registers that hold v
+        for (int o = 0; o < a.n_obs; ++o) {
+            double e = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) e += a.obs[size_t(o) * a.obs_ostride + bt * a.obs_bstride + xg_of(r)] * (acc[r].x * acc[r].x + acc[r].y * acc[r].y);
+            wg_atomic_add<NT>(e, a.expect_slot + o * a.exp_ostride + bt, red);
+        }
+    }
+    if (!a.has_q) {
+        if (BWD) flush_gradients();
+        return;
+    }
+
+    __syncthreads();  // all partner reads of u are done
+#pragma unroll
+    for (int r = 0; r < R; ++r) tile[unsigned(r) * NT + tid] = acc[r];
+    __syncthreads();
+
+    auto start_half = [&](auto hc) {
+        constexpr int h = decltype(hc)::value;
+        const double* __restrict__ cf = a.coef_sta + bt * a.coef_bstride;
+        const bool need_xs = BWD && (!REC || exact_sta);
+        double2 xs[RH];
+        if (need_xs) {
+#pragma unroll
+            for (int r = 0; r < RH; ++r) xs[r] = stream_load(a.x_sta + boff + xg_of(h * RH + r));
+        }
+        double2 q[RH];
+        const double dlane = lane_diag();
+#pragma unroll
+        for (int r = 0; r < RH; ++r) {
+            const int rf = h * RH + r;
+            double d = diag_of(rf, dlane);
+            const unsigned x = xg_of(rf) | rank_hi;
+            if (FAST) {
+                if (GD) d += cf[2] * double(a.dcnt[0] - popc_i(x & a.dmask[0]));
+            } else {
+                for (int g = 0; g < a.gd; ++g) d += cf[2 * a.ga + g] * double(a.dcnt[g] - popc_i(x & a.dmask[g]));
+            }
+            const double dr = a.sg_r + a.sb_r * d, di = a.sg_i + a.sb_i * d;
+            q[r].x = dr * acc[rf].x - di * acc[rf].y;
+            q[r].y = dr * acc[rf].y + di * acc[rf].x;
+        }
+        if (BWD && !REC) {  // Re(beta conj(mu) x): weight of d(x) in the gradient (REC: taken by the launch that completes the factor)
+            double rr[RH];
+#pragma unroll
+            for (int r = 0; r < RH; ++r) {
+                const int rf = h * RH + r;
+                const double pr = a.cb_sta_r * acc[rf].x + a.cb_sta_i * acc[rf].y, pi = a.cb_sta_i * acc[rf].x - a.cb_sta_r * acc[rf].y;
+                rr[r] = pr * xs[r].x - pi * xs[r].y;
+                if (a.wtot) unsafeAtomicAdd(a.wtot + (a.sh_bits ? boff : 0) + xg_of(rf), rr[r]);
+            }
+            for (int g = 0; g < GD; ++g) {
+                double sgd = 0.0;
+#pragma unroll
+                for (int r = 0; r < RH; ++r) sgd += rr[r] * double(a.dcnt[g] - popc_i((xg_of(h * RH + r) | rank_hi) & a.dmask[g]));
+                park1<NW>(sgd, red, 2 * a.ga + g);
+            }
+        }
+        for (int g = 0; g < GA; ++g) {
+            const uint32_t mask = a.sta_mask[g];
+            if (!FAST && !mask) continue;
+            double2 ts[RH], ds[RH];
+#pragma unroll
+            for (int r = 0; r < RH; ++r) {
+                ts[r] = make_double2(0.0, 0.0);
+                ds[r] = make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int b = 0; b < LT; ++b) {
+                if (FAST || (mask >> b & 1u)) {
+#pragma unroll
+                    for (int r = 0; r < RH; ++r) {
+                        const int rf = h * RH + r;
+                        const unsigned i = unsigned(rf) * NT + tid;
+                        double2 pv;
+                        if (b < LGT) pv = tile[i ^ (1u << b)];
+                        else pv = acc[rf ^ (1 << (b < LGT ? 0 : b - LGT))];
+                        ts[r].x += pv.x;
+                        ts[r].y += pv.y;
+                        if (CPLX) {
+                            const double sgn = (i >> b & 1u) ? 1.0 : -1.0;
+                            ds[r].x = fma(sgn, pv.x, ds[r].x);
+                            ds[r].y = fma(sgn, pv.y, ds[r].y);
+                        }
+                    }
+                }
+            }
+            const double cr = cf[g], ci = cf[a.ga + g];
+            const double k1r = a.sb_r * cr, k1i = a.sb_i * cr;
+            const double k2r = -a.sb_i * ci, k2i = a.sb_r * ci;
+#pragma unroll
+            for (int r = 0; r < RH; ++r) {
+                q[r].x += k1r * ts[r].x - k1i * ts[r].y;
+                q[r].y += k1r * ts[r].y + k1i * ts[r].x;
+                if (CPLX) {
+                    q[r].x += k2r * ds[r].x - k2i * ds[r].y;
+                    q[r].y += k2r * ds[r].y + k2i * ds[r].x;
+                }
+            }
+            if (BWD && exact_sta) {
+                double z1r = 0.0, z1i = 0.0, z2r = 0.0, z2i = 0.0;
+#pragma unroll
+                for (int r = 0; r < RH; ++r) {
+                    z1r += ts[r].x * xs[r].x + ts[r].y * xs[r].y;
+                    z1i += ts[r].x * xs[r].y - ts[r].y * xs[r].x;
+                    if (CPLX) {
+                        z2r += ds[r].x * xs[r].x + ds[r].y * xs[r].y;
+                        z2i += ds[r].x * xs[r].y - ds[r].y * xs[r].x;
+                    }
+                }
+                if (CPLX) park2<NW>(a.cb_sta_r * z1r - a.cb_sta_i * z1i, a.cb_sta_r * z2i + a.cb_sta_i * z2r, red, 2 * a.ga + a.gd + 2 * g,
+                                    2 * a.ga + a.gd + 2 * g + 1);
+                else park1<NW>(a.cb_sta_r * z1r - a.cb_sta_i * z1i, red, 2 * a.ga + a.gd + 2 * g);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RH; ++r) stream_store(a.q_out + boff + xg_of(h * RH + r), q[r]);
+    };
+    start_half(std::integral_constant<int, 0>{});
+    start_half(std::integral_constant<int, 1>{});
+    if (BWD) flush_gradients();
 }

@@ -40,10 +40,6 @@ constexpr int kMaxRemote = 6;  // up to 2^6 GPUs in a state-sharded run
 constexpr int kShardMaxBits = 6;  // natively driven sharded runs: up to 2^6 ranks
 
 static thread_local std::string g_last_error;  // the only mutable per-thread state (include/rydiff.h: rydiff_last_error)
-#ifndef RYDIFF_TILE_BITS
-#define RYDIFF_TILE_BITS 12
-#endif
-constexpr int kTileBitsHost = RYDIFF_TILE_BITS;
 
 static int fail(int code, const std::string& msg) {
     g_last_error = msg;
@@ -238,10 +234,9 @@ __global__ void k_build_udiag(double* __restrict__ udiag, const double* __restri
 }
 
 // split form of the interaction diagonal for one tile layout (chain_kernels.hpp):
-//   U(x) = utt[i] + vr[t][12] + sum_{tile bits a with n_a(i)=1} vr[t][a],   x = x(t, i)
+//   U(x) = utt[i] + vr[t][LT] + sum_{tile bits a with n_a(i)=1} vr[t][a],   x = x(t, i);   LT = 12 or 13 tile bits
 __global__ void k_build_split(double* __restrict__ utt, double* __restrict__ vr, const double* __restrict__ u_pairs,
-                              int N, int lo, int hs, int hb, unsigned tiles) {
-    constexpr int LT = kTileBitsHost;
+                              int N, int lo, int hs, int hb, unsigned tiles, int LT) {
     const unsigned id = blockIdx.x * blockDim.x + threadIdx.x;
     auto gbit = [&](int b) { return b < lo ? b : hs + (b - lo); };          // tile bit -> index bit
     auto upair = [&](int ib, int jb) {                                       // index bits -> U_ij
@@ -970,39 +965,43 @@ __global__ __launch_bounds__(64) void k_build_ptable(PTableArgs a) {
 }
 
 // ---- chained tile passes (chain_kernels.hpp) ------------------------------------------------------------------------
-// Tile layouts: every layout keeps a contiguous low run of >= 2^3 amplitudes so that global accesses stay coalesced.
-//   two layouts   (13 <= N <= 22):  A = [0,12)            B = [0,24-N) u [12,N)
-//   three layouts (23 <= N <= 28):  A = [0,12)            B = [0,4) u [12,20)        C = [0,32-N) u [20,N)
+// Tile layouts: every layout keeps a contiguous low run of amplitudes so that global accesses stay coalesced.  LT = tile bits:
+// 12 (k_chain: 64 KiB of LDS, 4 amplitudes per thread at 1024 threads) or 13 (k_chain_wide: 128 KiB, two register halves).
+//   two layouts:    A = [0,LT)            B = [0,2LT-N) u [LT,N)
+//   three layouts:  A = [0,LT)            B = [0,LT-8) u [LT,LT+8)        C = [0,2LT+8-N) u [LT+8,N)
 // With three layouts a factor takes two launches (start in A or C, middle pass in B, finish in C or A — the finishing
 // launch also starts the next factor), 4R+3W instead of 2R+2W: still far better than 16-byte runs in a two-layout B.
+// Which (LT, layout count) a chain uses: chain_geom() below.
 struct LayoutDesc {
     int lo, hs, hb;
     uint32_t bits;  // amplitude-index bits covered by the tile
 };
 
-// force_three (layout mode): 0 automatic; 1 = kernel variant 7 — three layouts wherever they are legal; 2 = kernel variant 11 — two
-// layouts up to 24 qubits (layout B then has runs of 32 / 16 bytes at 23 / 24 qubits).  Both for A/B tests.
-int chain_layout_count(int N, int force_three) {
-    if (force_three == 2 && N <= 24) return 2;
-    if (N >= 23 || (force_three == 1 && N >= 21)) return 3;
-    return 2;
+struct ChainGeom {
+    int lt;       // tile bits: kTileBits (12) or kWideTileBits (13)
+    int layouts;  // 2 or 3
+};
+
+// split-diagonal tables of one tile size: [3 layouts][2^LT + tiles * 16] doubles; one set per tile size (plan.hpp: off_split)
+double* split_tables(const Plan& pl, char* ws, int lt) {
+    return reinterpret_cast<double*>(ws + pl.off_split) + size_t(lt - kTileBits) * pl.split_set_doubles;
 }
 
-LayoutDesc chain_layout(int N, int which, int force_three) {
+LayoutDesc chain_layout(int N, int which, const ChainGeom& g) {
     LayoutDesc d{};
-    const bool three = chain_layout_count(N, force_three) == 3;
+    const bool three = g.layouts == 3;
     if (which == 0) {  // A
-        d.lo = kTileBits;
-        d.hs = kTileBits;
+        d.lo = g.lt;
+        d.hs = g.lt;
         d.hb = 0;
     } else if (which == 1) {  // B
-        d.hs = kTileBits;
-        d.hb = three ? 8 : N - kTileBits;
-        d.lo = kTileBits - d.hb;
+        d.hs = g.lt;
+        d.hb = three ? 8 : N - g.lt;
+        d.lo = g.lt - d.hb;
     } else {  // C (three-layout mode only)
-        d.hs = kTileBits + 8;
+        d.hs = g.lt + 8;
         d.hb = N - d.hs;
-        d.lo = kTileBits - d.hb;
+        d.lo = g.lt - d.hb;
     }
     d.bits = ((1u << d.lo) - 1u) | (((1u << d.hb) - 1u) << d.hs);
     return d;
@@ -1027,6 +1026,7 @@ struct Runtime {
     bool generic_direct = false;  // variant 9: direct kernels without the unrolled global-drive instantiations
     bool plain_tile_order = false;  // variant 12: no line-sharing tile swizzle (ChainArgs.tile_swz)
     int force_three = 0;          // 1: variant 7, three tile layouts wherever they are legal; 2: variant 11, two layouts up to 24 qubits
+    int tile_mode = 0;            // 0 automatic | 12: variant 13, 2^12-amplitude tiles everywhere | 13: variant 14, wide tiles from 14 qubits
     bool force_xcd = false;       // variant 10: trajectory-per-XCD placement of the chained tiles forced
     int chain_lgt = 9;            // log2(threads per tile workgroup) of explicitly chosen chained variants
     // state-sharded run: where the partner slabs arrive and who moves them (RydProblem.shard_recv / shard_exchange)
@@ -1040,12 +1040,13 @@ struct Runtime {
 // RydProblem.kernel_variant -> Runtime (include/rydiff.h lists the values)
 int decode_variant(const RydProblem* p, Runtime& rt) {
     int v = p->kernel_variant;
-    if (v < 0 || v > 12 || v == 5 || v == 6) return fail(RYDIFF_EINVAL, "kernel_variant must be 0..4 or 7..12");
+    if (v < 0 || v > 14 || v == 5 || v == 6) return fail(RYDIFF_EINVAL, "kernel_variant must be 0..4 or 7..14");
     rt.generic_direct = v == 9;
     if (v == 9) v = 1;
     rt.force_three = v == 7 ? 1 : (v == 11 ? 2 : 0);
     rt.plain_tile_order = v == 12;
-    if (v == 7 || v == 11 || v == 12) v = 0;
+    rt.tile_mode = v == 13 ? 12 : (v == 14 ? 13 : 0);
+    if (v == 7 || v == 11 || v == 12 || v == 13 || v == 14) v = 0;
     rt.force_xcd = v == 10;
     if (v == 10) v = 0;
     rt.variant = v;
@@ -1054,6 +1055,25 @@ int decode_variant(const RydProblem* p, Runtime& rt) {
     rt.shard_exchange = p->shard_exchange;
     rt.shard_user = p->shard_user;
     return RYDIFF_OK;
+}
+
+// Tile size and layout count of the chained passes of one direction (forward / adjoint chains are independent: what they share is
+// the complete vectors, which are in plain amplitude order).  Measured on MI355X (profiles/r03_wide_tiles.txt): 2^13-amplitude tiles
+// (k_chain_wide) win the forward pass at 21-24 qubits (two layouts up to 24: runs of 512 / 256 / 128 / 64 bytes) and the adjoint
+// pass of a phase-free drive there too; the adjoint WITH signed sums (drive phase gradients) spills 37 VGPRs in the wide form and
+// wins only at 22 and 23 qubits.  Explicit chained variants (2..4, 7, 10, 11) keep the 2^12 tiles they were written for.
+ChainGeom chain_geom(const Runtime& rt, bool bwd) {
+    const int N = rt.pl.NL;
+    const bool cplx = (rt.flags & 1) != 0 || (bwd && !rt.real_amp_grad);
+    int lt = kTileBits;
+    if (rt.tile_mode == 13) lt = N > kWideTileBits ? kWideTileBits : kTileBits;
+    else if (rt.tile_mode == 0 && rt.variant == 0 && !rt.force_three && !rt.force_xcd && N >= 21 && N <= 24)
+        lt = (bwd && cplx && (N == 21 || N == 24)) ? kTileBits : kWideTileBits;
+    ChainGeom g{lt, 2};
+    if (lt == kWideTileBits) g.layouts = N <= 24 ? 2 : 3;
+    else if (rt.force_three == 2 && N <= 24) g.layouts = 2;
+    else if (N >= 23 || (rt.force_three == 1 && N >= 21)) g.layouts = 3;
+    return g;
 }
 
 // metadata words -> device through kernel arguments (k_upload): asynchronous, the host buffer may die on return
@@ -1206,7 +1226,7 @@ void fill_info(const Runtime& rt, double lo, double hi, size_t ws, RydPlanInfo* 
 // 83 vs 78 ms).  Explicit kernel variants are left alone (A/B tests).
 bool few_tiles(const Runtime& rt, bool with_gradients) {
     const Plan& pl = rt.pl;
-    if (rt.variant != 0 || rt.force_three || rt.force_xcd || pl.shard_bits) return false;
+    if (rt.variant != 0 || rt.force_three || rt.force_xcd || rt.tile_mode == kWideTileBits || pl.shard_bits) return false;
     // forward only: crossover at 2^18 amplitudes in flight (N = 19: 12.5 us direct vs 10.8 us chained per pass).  With gradients the
     // direct ADJOINT pass (own tape element only, partner reads of the cotangent served by L2) stays ahead of the chained one up to
     // 2^19 (11.6-12.8 vs 14.0-14.7 us) and the pair of passes wins by 1-7 % there (profiles/r02_crossover_direct_vs_chained.txt);
@@ -1303,15 +1323,23 @@ int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_
     }
     if (pl.NL > kTileBits && pl.NL <= 28) {  // split diagonal for the tile layouts of the chained passes
         // (sharded runs: the layouts of the NL slab qubits, rows for every tile of the WHOLE register — rank bits on top)
-        const unsigned tiles = unsigned((size_t(1) << pl.N) >> kTileBits);
-        double* split = reinterpret_cast<double*>(ws + pl.off_split);
-        const size_t per_layout = kTileAmps + size_t(tiles) * 16;
-        for (int l = 0; l < chain_layout_count(pl.NL, rt.force_three); ++l) {
-            const LayoutDesc d = chain_layout(pl.NL, l, rt.force_three);
-            double* utt = split + l * per_layout;
-            hipLaunchKernelGGL(k_build_split, dim3((kTileAmps + tiles + 255) / 256), dim3(256), 0, stream, utt, utt + kTileAmps,
-                               p->u_pairs, pl.N, d.lo, d.hs, d.hb, tiles);
-            LAUNCH_CHECK();
+        // one table set per tile size in use (the forward and the adjoint chains choose theirs independently: chain_geom)
+        bool built[2] = {false, false};
+        for (int bwd = 0; bwd <= (need_backward ? 1 : 0); ++bwd) {
+            const ChainGeom g = chain_geom(rt, bwd != 0);
+            if (built[g.lt - kTileBits]) continue;
+            built[g.lt - kTileBits] = true;
+            const unsigned tiles = unsigned((size_t(1) << pl.N) >> g.lt);
+            const size_t tile_amps = size_t(1) << g.lt;
+            double* split = split_tables(pl, ws, g.lt);
+            const size_t per_layout = tile_amps + size_t(tiles) * 16;
+            for (int l = 0; l < g.layouts; ++l) {
+                const LayoutDesc d = chain_layout(pl.NL, l, g);
+                double* utt = split + l * per_layout;
+                hipLaunchKernelGGL(k_build_split, dim3(unsigned((tile_amps + tiles + 255) / 256)), dim3(256), 0, stream, utt, utt + tile_amps,
+                                   p->u_pairs, pl.N, d.lo, d.hs, d.hb, tiles, g.lt);
+                LAUNCH_CHECK();
+            }
         }
     }
     return RYDIFF_OK;
@@ -1443,25 +1471,25 @@ struct KernelStep {
     int sta;
 };
 
-void chain_schedule(int N, int force_three, int F, std::vector<KernelStep>& ks) {
+void chain_schedule(int N, const ChainGeom& geom, int F, std::vector<KernelStep>& ks) {
     ks.clear();
-    if (chain_layout_count(N, force_three) == 2) {
+    if (geom.layouts == 2) {
         for (int k = 0; k <= F; ++k)
-            ks.push_back({k & 1, k > 0 ? chain_layout(N, (k - 1) & 1, force_three).bits : 0u, k - 1, true, k < F ? k : -1});
+            ks.push_back({k & 1, k > 0 ? chain_layout(N, (k - 1) & 1, geom).bits : 0u, k - 1, true, k < F ? k : -1});
         return;
     }
-    const uint32_t bbits = chain_layout(N, 1, force_three).bits;
+    const uint32_t bbits = chain_layout(N, 1, geom).bits;
     auto end_layout = [](int m) { return (m & 1) ? 2 : 0; };  // factor m starts in A (even m) or C (odd m)
     for (int m = 0; m <= F; ++m) {
-        const uint32_t cov = m > 0 ? (chain_layout(N, end_layout(m - 1), force_three).bits | bbits) : 0u;
+        const uint32_t cov = m > 0 ? (chain_layout(N, end_layout(m - 1), geom).bits | bbits) : 0u;
         ks.push_back({end_layout(m), cov, m - 1, true, m < F ? m : -1});
-        if (m < F) ks.push_back({1, chain_layout(N, end_layout(m), force_three).bits, m, false, -1});
+        if (m < F) ks.push_back({1, chain_layout(N, end_layout(m), geom).bits, m, false, -1});
     }
 }
 
-uint32_t to_tile_mask(const LayoutDesc& d, uint32_t index_mask) {
+uint32_t to_tile_mask(const LayoutDesc& d, int lt, uint32_t index_mask) {
     uint32_t m = 0;
-    for (int b = 0; b < kTileBits; ++b) {
+    for (int b = 0; b < lt; ++b) {
         const int gb = b < d.lo ? b : d.hs + (b - d.lo);
         if (index_mask >> gb & 1u) m |= 1u << b;
     }
@@ -1502,17 +1530,20 @@ struct ChainStep {
     long exp_ostride = 0;
 };
 
-template <int LGT, bool CPLX, bool BWD, bool FAST = false, bool RES = false>
+template <int LT, int LGT, bool CPLX, bool BWD, bool FAST = false, bool RES = false>
 int launch_chain_t(const ChainArgs& ca, unsigned tiles, hipStream_t stream) {
+    static_assert(LT == kTileBits || (LT == kWideTileBits && LGT == 10 && !RES), "wide tiles: 1024 threads, no L2-resident placement");
     if constexpr (!FAST) {  // one global drive, at most one detuning group: the loop-free instantiation
-        if (ca.ga == 1 && ca.gd <= 1 && ca.sta_mask[0] == (1u << kTileBits) - 1u)
-            return launch_chain_t<LGT, CPLX, BWD, true, RES>(ca, tiles, stream);
+        if (ca.ga == 1 && ca.gd <= 1 && ca.sta_mask[0] == (1u << LT) - 1u)
+            return launch_chain_t<LT, LGT, CPLX, BWD, true, RES>(ca, tiles, stream);
     }
     // tile + reduction scratch: one double per wave (forward), [4 ga + gd] slots per wave (adjoint: parked gradient partials)
     const size_t nw = (size_t(1) << LGT) / 64;
-    const size_t max_lds = (size_t(1) << kTileBits) * sizeof(double2) + 256 + (BWD ? size_t(5) * kMaxGroups * nw * sizeof(double) : 0);
-    const size_t lds = (size_t(1) << kTileBits) * sizeof(double2) + 256 + (BWD ? size_t(4 * ca.ga + ca.gd) * nw * sizeof(double) : 0);
-    auto kern = k_chain<kTileBits, LGT, CPLX, BWD, FAST, RES>;
+    const size_t max_lds = (size_t(1) << LT) * sizeof(double2) + 256 + (BWD ? size_t(5) * kMaxGroups * nw * sizeof(double) : 0);
+    const size_t lds = (size_t(1) << LT) * sizeof(double2) + 256 + (BWD ? size_t(4 * ca.ga + ca.gd) * nw * sizeof(double) : 0);
+    void (*kern)(ChainArgs);
+    if constexpr (LT == kWideTileBits) kern = k_chain_wide<LT, CPLX, BWD, FAST>;  // two register halves (k_chain<13, ...> would spill)
+    else kern = k_chain<LT, LGT, CPLX, BWD, FAST, RES>;
     // once per instantiation and process; idempotent, so a race between two first callers is harmless
     static std::atomic<bool> attr_set{false};
     if (!attr_set.load(std::memory_order_acquire)) {
@@ -1525,12 +1556,12 @@ int launch_chain_t(const ChainArgs& ca, unsigned tiles, hipStream_t stream) {
     return RYDIFF_OK;
 }
 
-template <int LGT, bool RES = false>
+template <int LT, int LGT, bool RES = false>
 int launch_chain_l(const ChainArgs& ca, unsigned tiles, bool cplx, bool bwd, hipStream_t stream) {
     // the adjoint needs both partner sums (plain and signed) unless the coefficients are real AND the caller only uses the
     // real part of the amplitude gradients (RydProblem.real_amp_grad): then `cplx` arrives false here
-    if (bwd) return cplx ? launch_chain_t<LGT, true, true, false, RES>(ca, tiles, stream) : launch_chain_t<LGT, false, true, false, RES>(ca, tiles, stream);
-    return cplx ? launch_chain_t<LGT, true, false, false, RES>(ca, tiles, stream) : launch_chain_t<LGT, false, false, false, RES>(ca, tiles, stream);
+    if (bwd) return cplx ? launch_chain_t<LT, LGT, true, true, false, RES>(ca, tiles, stream) : launch_chain_t<LT, LGT, false, true, false, RES>(ca, tiles, stream);
+    return cplx ? launch_chain_t<LT, LGT, true, false, false, RES>(ca, tiles, stream) : launch_chain_t<LT, LGT, false, false, false, RES>(ca, tiles, stream);
 }
 
 // cotangents handed to the backward call (fused injection, see ChainArgs / FactorBwdArgs)
@@ -1550,17 +1581,19 @@ struct BatchSlice {
 
 int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, const BatchSlice& bs, const InjectSource& inj, hipStream_t stream) {
     const Plan& pl = rt.pl;
-    const LayoutDesc X = chain_layout(pl.NL, cs.layout, rt.force_three);
+    const ChainGeom geom = chain_geom(rt, cs.bwd);
+    const LayoutDesc X = chain_layout(pl.NL, cs.layout, geom);
     ChainArgs ca{};
     ca.u = cs.u;
     ca.p = cs.p ? cs.p : cs.u;  // (always loadable: the kernel requests u, p and the tape vectors outside of control flow)
     ca.v_out = cs.v_out;
     ca.q_out = cs.q_out;
     {
-        const size_t per_layout = kTileAmps + size_t((size_t(1) << pl.N) >> kTileBits) * 16;
-        const double* split = reinterpret_cast<const double*>(ws + pl.off_split) + size_t(cs.layout) * per_layout;
+        const size_t tile_amps = size_t(1) << geom.lt;
+        const size_t per_layout = tile_amps + size_t((size_t(1) << pl.N) >> geom.lt) * 16;
+        const double* split = split_tables(pl, ws, geom.lt) + size_t(cs.layout) * per_layout;
         ca.utt = split;
-        ca.vr = split + kTileAmps;
+        ca.vr = split + tile_amps;
     }
     const double* coef = reinterpret_cast<const double*>(ws + pl.off_coef);
     ca.coef_fin = coef + size_t(std::max(cs.fin_stage, 0)) * pl.NC;
@@ -1590,8 +1623,8 @@ int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, const BatchSl
     ca.b_count = bs.count;
     const uint32_t prev_bits = cs.covered_bits;
     for (int g = 0; g < pl.ga.n; ++g) {
-        ca.fin_mask[g] = to_tile_mask(X, pl.ga.amp_index_mask[g] & ~prev_bits);
-        ca.sta_mask[g] = to_tile_mask(X, pl.ga.amp_index_mask[g]);
+        ca.fin_mask[g] = to_tile_mask(X, geom.lt, pl.ga.amp_index_mask[g] & ~prev_bits);
+        ca.sta_mask[g] = to_tile_mask(X, geom.lt, pl.ga.amp_index_mask[g]);
     }
     for (int g = 0; g < pl.gd.n; ++g) {
         ca.dmask[g] = pl.gd.amp_index_mask[g];
@@ -1634,18 +1667,19 @@ int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, const BatchSl
             ca.inj_ostride = long(pl.T + 1) * pl.B;
         }
     }
-    const unsigned tiles = unsigned(pl.dim >> kTileBits);
+    const unsigned tiles = unsigned(pl.dim >> geom.lt);
     if (X.lo < 3 && !bs.xcd && !rt.plain_tile_order && tiles % (8u << (3 - X.lo)) == 0) ca.tile_swz = 3 - X.lo;
     const bool cplx = (rt.flags & 1) != 0 || (cs.bwd && !rt.real_amp_grad);
     // auto: 1024 threads per tile for the forward passes, 512 for the (register-hungrier) adjoint passes
     // (the real-drive adjoint, without the signed sums, fits 1024 threads too: measured 2710 -> 2767 steps/s on C3)
     const int lgt = rt.variant == 0 ? ((cs.bwd && cplx) ? 9 : 10) : rt.chain_lgt;
+    if (geom.lt == kWideTileBits) return launch_chain_l<kWideTileBits, 10>(ca, tiles, cplx, cs.bwd, stream);
     if (bs.xcd)  // L2-resident placement (automatic thread counts only: variant 10 decodes to 0)
-        return lgt == 9 ? launch_chain_l<9, true>(ca, tiles, cplx, cs.bwd, stream) : launch_chain_l<10, true>(ca, tiles, cplx, cs.bwd, stream);
+        return lgt == 9 ? launch_chain_l<kTileBits, 9, true>(ca, tiles, cplx, cs.bwd, stream) : launch_chain_l<kTileBits, 10, true>(ca, tiles, cplx, cs.bwd, stream);
     switch (lgt) {
-        case 8: return launch_chain_l<8>(ca, tiles, cplx, cs.bwd, stream);
-        case 10: return launch_chain_l<10>(ca, tiles, cplx, cs.bwd, stream);
-        default: return launch_chain_l<9>(ca, tiles, cplx, cs.bwd, stream);
+        case 8: return launch_chain_l<kTileBits, 8>(ca, tiles, cplx, cs.bwd, stream);
+        case 10: return launch_chain_l<kTileBits, 10>(ca, tiles, cplx, cs.bwd, stream);
+        default: return launch_chain_l<kTileBits, 9>(ca, tiles, cplx, cs.bwd, stream);
     }
 }
 
@@ -1661,7 +1695,7 @@ int run_chain(const Runtime& rt, char* ws, const std::vector<ChainItem>& items, 
     const int F = int(items.size()) - (skip_last_finish ? 1 : 0);  // the last factor is not even started then
     if (F <= 0) return RYDIFF_OK;
     std::vector<KernelStep> ks;
-    chain_schedule(pl.NL, rt.force_three, F, ks);
+    chain_schedule(pl.NL, chain_geom(rt, false), F, ks);
     const double2* cur = start;
     int rcx = shard_signal(rt, 0, cur);  // partners need the chain's start vector for the first completing launch
     if (rcx) return rcx;
@@ -1723,7 +1757,7 @@ int run_chain_bwd(const Runtime& rt, char* ws, const std::vector<ChainItem>& ite
     double2* pp[2] = {reinterpret_cast<double2*>(ws + pl.off_pp0), reinterpret_cast<double2*>(ws + pl.off_pp1)};
     const int M = int(items.size());
     std::vector<KernelStep> ks;
-    chain_schedule(pl.NL, rt.force_three, M, ks);
+    chain_schedule(pl.NL, chain_geom(rt, true), M, ks);
     const double2* cur = lam_in;
     int rcx = shard_signal(rt, 0, cur);  // sharded: the partners need the incoming cotangent for the first completing launch
     if (rcx) return rcx;
@@ -1979,7 +2013,7 @@ namespace {
 // group size (0: off).  Placement changes speed only: results are the same as with the plain grid (A/B-tested).
 int xcd_group_size(const Runtime& rt, bool adjoint) {
     const Plan& pl = rt.pl;
-    if (!chain_enabled(rt) || chain_layout_count(pl.N, rt.force_three) != 2 || pl.shard_bits) return 0;
+    if (!chain_enabled(rt) || chain_geom(rt, adjoint).layouts != 2 || chain_geom(rt, adjoint).lt != kTileBits || pl.shard_bits) return 0;
     const size_t live = size_t(32) << pl.N;    // complete vector + partial of one trajectory
     const size_t budget = size_t(3) << 20;     // of the 4 MiB L2 (the rest: tape lines on their way out, tables)
     const int m = int(std::max<size_t>(1, budget / live));
@@ -2004,8 +2038,12 @@ void describe_kernels(const Runtime& rt, const RydProblem* p, bool backward, Ryd
             const bool cplx = (rt.flags & 1) != 0 || (bwd && !p->real_amp_grad);
             const int lgt = rt.variant == 0 ? ((bwd && cplx) ? 9 : 10) : rt.chain_lgt;
             const bool res = xcd_group_size(rt, bwd != 0) > 0;
-            std::snprintf(bwd ? info->kernel_bwd : info->kernel_fwd, sizeof(info->kernel_fwd), "k_chain<%d,%d,%s,%s,%s,%s>", kTileBits, lgt,
-                          b(cplx), b(bwd != 0), b(fast), b(res));
+            if (chain_geom(rt, bwd != 0).lt == kWideTileBits)
+                std::snprintf(bwd ? info->kernel_bwd : info->kernel_fwd, sizeof(info->kernel_fwd), "k_chain_wide<%d,%s,%s,%s>", kWideTileBits,
+                              b(cplx), b(bwd != 0), b(fast));
+            else
+                std::snprintf(bwd ? info->kernel_bwd : info->kernel_fwd, sizeof(info->kernel_fwd), "k_chain<%d,%d,%s,%s,%s,%s>", kTileBits, lgt,
+                              b(cplx), b(bwd != 0), b(fast), b(res));
         }
     } else if (info->kernel_family == 2) {
         if (direct_global_ok(rt)) {

@@ -73,7 +73,7 @@ def test_virtual_sharded_gradients_match_single_gpu_adjoint(cuda_device, n_qubit
 
 
 @pytest.mark.parametrize("n_qubits,g,variant,tape", [(6, 1, 0, 1), (11, 2, 0, 1), (13, 3, 0, 1), (15, 2, 0, 1), (16, 3, 0, 1), (16, 3, 2, 1), (17, 1, 0, 1),
-                                                     (16, 2, 1, 1)])
+                                                     (16, 2, 1, 1), (17, 3, 14, 1), (16, 2, 14, 1)])  # 14: wide tiles (slabs of 14 qubits)
 def test_native_sharded_gradients_match_single_gpu_adjoint(cuda_device, n_qubits, g, variant, tape):
     """K6 completed: the REVERSE sweep of a state-sharded run driven by the library — rydiff_forward with the
     slabs' trajectory on the workspace tape, then rydiff_backward: cotangent slabs through the same partner reads as the state
@@ -106,13 +106,14 @@ def test_native_sharded_gradients_match_single_gpu_adjoint(cuda_device, n_qubits
     assert rel_err(out["g_u"], u.grad.cpu().numpy()) < 1e-9
 
 
-def test_native_sharded_gradients_of_a_phase_free_global_drive(cuda_device):
+@pytest.mark.parametrize("n_qubits,g,variant", [(16, 3, 0), (17, 3, 14)])  # 14: wide tiles (k_chain_wide) on the 14-qubit slabs
+def test_native_sharded_gradients_of_a_phase_free_global_drive(cuda_device, n_qubits, g, variant):
     """The same through the single-tape-read adjoint instantiation (one global drive without phase: the drive gradient is RECOVERED
     from the completed cotangent, which then already contains the partner slabs' part) — the shape of BASELINE config 5."""
+    from pulser_diff_amd import _native
     from pulser_diff_amd.sharded import grad_virtual_native
     from pulser_diff_amd.solver import SolverType, evolve
 
-    n_qubits, g = 16, 3
     terms = random_terms(n_qubits, 17, 0.002, seed=777, local=False, phase=False)
     from pulser_diff_amd.sharded import ShardedProblem
 
@@ -128,7 +129,11 @@ def test_native_sharded_gradients_of_a_phase_free_global_drive(cuda_device):
         t.requires_grad_(True)
     _, expect = evolve(amp, det, u, tsave, psi0.T.contiguous().to(cuda_device), spec, zd[None])
     (expect[0, :, 0] * w.to(cuda_device)).sum().backward()
-    out = grad_virtual_native(prob, psi0[:, 0].to(cuda_device), tsave.numpy(), zd, w.numpy())
+    _native.set_kernel_variant(variant)
+    try:
+        out = grad_virtual_native(prob, psi0[:, 0].to(cuda_device), tsave.numpy(), zd, w.numpy())
+    finally:
+        _native.set_kernel_variant(0)
     assert out["stats"]["kernel_family"] == "chained-tiles"
     assert np.abs(out["expect"].cpu().numpy() - expect[0, :, 0].detach().cpu().numpy()).max() < 1e-10
     assert rel_err(out["g_amp"].real, amp.grad[0].real.cpu().numpy()) < 1e-9
@@ -136,7 +141,7 @@ def test_native_sharded_gradients_of_a_phase_free_global_drive(cuda_device):
     assert rel_err(out["g_u"], u.grad.cpu().numpy()) < 1e-9
 
 
-@pytest.mark.parametrize("n_qubits,g,variant", [(5, 1, 0), (8, 3, 0), (12, 2, 0), (14, 1, 0), (15, 2, 0), (16, 3, 0), (17, 3, 4), (16, 2, 1),
+@pytest.mark.parametrize("n_qubits,g,variant", [(5, 1, 0), (8, 3, 0), (12, 2, 0), (14, 1, 0), (15, 2, 0), (16, 3, 0), (17, 3, 4), (16, 2, 1), (17, 3, 14),
                                                 (24, 3, 0)])  # the last one: BASELINE config 5's own shape (8 slabs of 2^21)
 def test_native_sharded_run_matches_single_gpu_solver(cuda_device, n_qubits, g, variant):
     """K6: the WHOLE sharded trajectory in one native call (RydProblem.shard_bits): slabs as trajectories, the rank qubits'

@@ -247,12 +247,18 @@ def _run_variant(variant, terms, tsave, psi_bd, device, obs, grads=True, batch_t
 
 @pytest.mark.parametrize("n_qubits,local,variant", [(13, True, 2), (14, False, 3), (16, True, 4), (17, True, 2), (20, False, 2),
                                                      (22, False, 4), (21, True, 7), (22, True, 7), (23, True, 0), (24, False, 0), (25, True, 0),
-                                                     (22, True, 0), (22, False, 12), (23, False, 11), (24, True, 11)])
+                                                     (22, True, 0), (22, False, 12), (23, False, 11), (24, True, 11),
+                                                     # wide (2^13-amplitude) tiles: automatic at 21..24 qubits (above), forced at small and
+                                                     # large sizes (14: three layouts from 25), and the 2^12 tiles kept selectable (13)
+                                                     (14, True, 14), (17, False, 14), (21, False, 0), (24, True, 0), (25, True, 14), (25, False, 14),
+                                                     (22, True, 13), (23, False, 13)])
 def test_chained_tile_kernels_match_direct_kernels(cuda_device, n_qubits, local, variant):
     """A/B on the GPU: the chained LDS-tile kernels (two tile layouts up to 22 qubits, three from 23 — variant 7 forces
     three wherever legal, variant 11 two up to 24 qubits; where a layout's runs are shorter than a 128-byte line the tiles that
     share lines are mapped to one XCD, variant 12 keeps the plain tile order) against the one-amplitude-per-thread kernels (which are themselves pinned to the oracle
-    above) — states, expectation values and gradients, complex coefficients."""
+    above) — states, expectation values and gradients, complex coefficients.  Round 3: 2^13-amplitude "wide" tiles (k_chain_wide: two
+    register halves per thread; two layouts up to 24 qubits) are the automatic choice at 21..24 qubits; variant 14 forces them from 14
+    qubits (three layouts from 25), variant 13 keeps the 2^12 tiles."""
     terms = random_terms(n_qubits, 17, 0.002, seed=200 + n_qubits, local=local)
     tsave = torch.linspace(0, 0.03, 7, dtype=torch.float64)
     gen = torch.Generator().manual_seed(n_qubits)

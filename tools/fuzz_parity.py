@@ -57,7 +57,7 @@ for case in range(n_cases):
     cond = (True,) * ka if three else ()
     ones = ((bool(rng.integers(0, 2)),) * kd) if three else ()
     out = {}
-    variants = (1, 0) + ((int(rng.choice([2, 4, 10])),) if n >= 13 else ())  # 10: trajectory-per-XCD placement  # from 13 qubits also the chained tiles FORCED: auto routes small single trajectories to the direct kernels
+    variants = (1, 0) + ((int(rng.choice([2, 4, 10, 14])),) if n >= 13 else ())  # 10: trajectory-per-XCD placement, 14: wide tiles  # from 13 qubits also the chained tiles FORCED: auto routes small single trajectories to the direct kernels
     for variant in variants:
         _native.set_kernel_variant(variant)
         spec = ProblemSpec(n, dt, ns, am, dm, solver=solver, store_states=store, tape=tape, amp_conditioned=cond, det_ones=ones)
