@@ -605,12 +605,12 @@ def run_c5(args, rank: int, world: int, device, barrier) -> dict:
     if virtual_bits:
         psi0 = torch.zeros(1 << n, dtype=torch.complex128, device=device)
         psi0[-1] = 1
-        run = lambda ts: S.run_virtual_native(prob, psi0, ts)[:2]  # noqa: E731
+        run = lambda ts: S.run_virtual_native(prob, psi0, ts)  # noqa: E731
     else:
         psi0 = torch.zeros(dloc, dtype=torch.complex128, device=device)
         if rank == world - 1:
             psi0[-1] = 1
-        run = lambda ts: S.run_distributed_native(prob, psi0, ts)[:2]  # noqa: E731
+        run = lambda ts: S.run_distributed_native(prob, psi0, ts)  # noqa: E731
     for _ in range(max(args.warmup, 1)):
         run(tsave[:3])
     # per-call set-up (plan, interaction tables of every slab, first-touch of the workspace) is paid once per trajectory whatever
@@ -623,7 +623,7 @@ def run_c5(args, rank: int, world: int, device, barrier) -> dict:
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        final, _ = run(tsave)
+        final, _, run_stats = run(tsave)
     barrier()
     elapsed = time.perf_counter() - t0
     nrm = (final.abs() ** 2).sum().reshape(1)
@@ -655,7 +655,7 @@ def run_c5(args, rank: int, world: int, device, barrier) -> dict:
                    "n_qubits": n, "time_steps": T, "ranks": world, "virtual_ranks": (1 << virtual_bits) if virtual_bits else 0,
                    "matvecs_per_step_fwd": plan.degree, "parallelism": f"state-sharded x{world}: top {prob.n_gpu_bits} qubit(s) select the rank"},
         "final_norm": float(nrm.item()),
-        "roofline": {"bound": "hbm", "applies": world == 1, "kernel": "k_chain (local factor pass of every slab, partner slabs added by the completing launch; whole run in one native call)",
+        "roofline": {"bound": "hbm", "applies": world == 1, "kernel": f"{run_stats.get('kernel_fwd') or 'k_chain'} (local factor pass of every slab, partner slabs added by the completing launch; whole run in one native call)",
                      "achieved": 32.0 * (1 << n) / (us_pass * 1e-6) / 1e9, "peak": HBM_PEAK_GBS * max(world, 1), "unit": "GB/s",
                      "frac": 32.0 * (1 << n) / (us_pass * 1e-6) / 1e9 / (HBM_PEAK_GBS * max(world, 1)), "traffic": None,
                      "avg_launch_us": us_pass, "algorithmic_bytes_per_launch": 32.0 * (1 << n),

@@ -692,10 +692,19 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
 // diagonal and output exist for FOUR amplitudes at a time.  In the finish stage every partner comes from LDS, in the start stage
 // the three register bits are register renaming as in k_chain.  No trajectory-per-XCD placement (registers of this size are never
 // L2-resident).  The arithmetic per amplitude is that of k_chain, statement by statement.
-template <int LT, bool CPLX, bool BWD, bool FAST>
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// RH: amplitudes per thread that are worked on together (R / RH passes over the register file: halves or quarters)
+template <int LT, bool CPLX, bool BWD, bool FAST, int RH = (1 << (LT - 10)) / 2>
 __global__ __launch_bounds__(1024) void k_chain_wide(ChainArgs a) {
-    constexpr int LGT = 10, NT = 1 << LGT, R = 1 << (LT - LGT), RH = R / 2, NW = NT / 64;
-    static_assert(R == 8, "two halves of four amplitudes per thread");
+    constexpr int LGT = 10, NT = 1 << LGT, R = 1 << (LT - LGT), NP = R / RH, NW = NT / 64;
+    static_assert(R >= 2 && RH >= 1 && NP * RH == R, "R amplitudes per thread in NP parts of RH");
     constexpr bool REC = BWD && FAST && !CPLX;
     const int GA = FAST ? 1 : a.ga;
     const int GD = FAST ? (a.gd ? 1 : 0) : a.gd;
@@ -770,7 +779,7 @@ __global__ __launch_bounds__(1024) void k_chain_wide(ChainArgs a) {
     {
         double2 uu[RH];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {  // u goes straight to LDS, four amplitudes at a time
+        for (int h = 0; h < NP; ++h) {  // u goes straight to LDS, RH amplitudes at a time
 #pragma unroll
             for (int r = 0; r < RH; ++r) uu[r] = stream_load(a.u + boff + xg_of(h * RH + r));
 #pragma unroll
@@ -925,8 +934,7 @@ __global__ __launch_bounds__(1024) void k_chain_wide(ChainArgs a) {
             for (int r = 0; r < RH; ++r) stream_store(a.v_out + boff + xg_of(h * RH + r), acc[h * RH + r]);
         }
     };
-    finish_half(std::integral_constant<int, 0>{});
-    finish_half(std::integral_constant<int, 1>{});
+    static_for<0, NP>(finish_half);
 
     if (!BWD && a.obs) {  // <v|O|v> for diagonal observables, straight from the registers that hold v
         for (int o = 0; o < a.n_obs; ++o) {
@@ -1047,7 +1055,6 @@ __global__ __launch_bounds__(1024) void k_chain_wide(ChainArgs a) {
 #pragma unroll
         for (int r = 0; r < RH; ++r) stream_store(a.q_out + boff + xg_of(h * RH + r), q[r]);
     };
-    start_half(std::integral_constant<int, 0>{});
-    start_half(std::integral_constant<int, 1>{});
+    static_for<0, NP>(start_half);
     if (BWD) flush_gradients();
 }

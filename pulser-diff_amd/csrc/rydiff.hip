@@ -1059,16 +1059,17 @@ int decode_variant(const RydProblem* p, Runtime& rt) {
 
 // Tile size and layout count of the chained passes of one direction (forward / adjoint chains are independent: what they share is
 // the complete vectors, which are in plain amplitude order).  Measured on MI355X (profiles/r03_wide_tiles.txt): 2^13-amplitude tiles
-// (k_chain_wide) win the forward pass at 21-24 qubits (two layouts up to 24: runs of 512 / 256 / 128 / 64 bytes) and the adjoint
-// pass of a phase-free drive there too; the adjoint WITH signed sums (drive phase gradients) spills 37 VGPRs in the wide form and
-// wins only at 22 and 23 qubits.  Explicit chained variants (2..4, 7, 10, 11) keep the 2^12 tiles they were written for.
+// (k_chain_wide) win the forward and the adjoint passes at 21-24 qubits (two layouts up to 24: runs of 512 / 256 / 128 / 64 bytes);
+// the adjoint WITH signed sums (drive phase gradients) works in register quarters there (in halves it spilled 37 VGPRs and lost at
+// 21 and 24 qubits).  Explicit chained variants (2..4, 7, 10, 11) keep the 2^12 tiles they were written for.  (`bwd` is kept in the
+// signature: the two directions choose independently, split-diagonal tables exist per tile size.)
 ChainGeom chain_geom(const Runtime& rt, bool bwd) {
+    (void)bwd;
     const int N = rt.pl.NL;
-    const bool cplx = (rt.flags & 1) != 0 || (bwd && !rt.real_amp_grad);
     int lt = kTileBits;
     if (rt.tile_mode == 13) lt = N > kWideTileBits ? kWideTileBits : kTileBits;
     else if (rt.tile_mode == 0 && rt.variant == 0 && !rt.force_three && !rt.force_xcd && N >= 21 && N <= 24)
-        lt = (bwd && cplx && (N == 21 || N == 24)) ? kTileBits : kWideTileBits;
+        lt = kWideTileBits;
     ChainGeom g{lt, 2};
     if (lt == kWideTileBits) g.layouts = N <= 24 ? 2 : 3;
     else if (rt.force_three == 2 && N <= 24) g.layouts = 2;
@@ -1542,8 +1543,11 @@ int launch_chain_t(const ChainArgs& ca, unsigned tiles, hipStream_t stream) {
     const size_t max_lds = (size_t(1) << LT) * sizeof(double2) + 256 + (BWD ? size_t(5) * kMaxGroups * nw * sizeof(double) : 0);
     const size_t lds = (size_t(1) << LT) * sizeof(double2) + 256 + (BWD ? size_t(4 * ca.ga + ca.gd) * nw * sizeof(double) : 0);
     void (*kern)(ChainArgs);
-    if constexpr (LT == kWideTileBits) kern = k_chain_wide<LT, CPLX, BWD, FAST>;  // two register halves (k_chain<13, ...> would spill)
-    else kern = k_chain<LT, LGT, CPLX, BWD, FAST, RES>;
+    if constexpr (LT == kWideTileBits) {  // register halves — quarters for the adjoint with signed sums (k_chain<13, ...> would spill)
+        kern = k_chain_wide<LT, CPLX, BWD, FAST, (BWD && CPLX) ? 2 : 4>;
+    } else {
+        kern = k_chain<LT, LGT, CPLX, BWD, FAST, RES>;
+    }
     // once per instantiation and process; idempotent, so a race between two first callers is harmless
     static std::atomic<bool> attr_set{false};
     if (!attr_set.load(std::memory_order_acquire)) {

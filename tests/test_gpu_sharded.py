@@ -168,13 +168,16 @@ def test_native_sharded_run_matches_single_gpu_solver(cuda_device, n_qubits, g, 
     assert np.abs(e_sh.cpu().numpy() - expect[0, :, 0].cpu().numpy()).max() < 1e-10
 
 
-def _two_rank_worker(rank, world, port, n_qubits, g, seed, out_q, backend="gloo"):
+def _two_rank_worker(rank, world, port, n_qubits, g, seed, out_q, backend="gloo", variant=0):
     import datetime
     import os
 
     import torch.distributed as dist
 
+    from pulser_diff_amd import _native
     from pulser_diff_amd.sharded import run_distributed_native
+
+    _native.set_kernel_variant(variant)
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     if backend == "nccl":  # RCCL: one GPU per rank, slabs over xGMI (posted from the library's exchange callback)
@@ -199,10 +202,11 @@ def _two_rank_worker(rank, world, port, n_qubits, g, seed, out_q, backend="gloo"
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_qubits,g", [(9, 1), (15, 2)])
-def test_native_sharded_run_over_processes(cuda_device, n_qubits, g):
+@pytest.mark.parametrize("n_qubits,g,variant", [(9, 1, 0), (15, 2, 0), (15, 1, 14)])
+def test_native_sharded_run_over_processes(cuda_device, n_qubits, g, variant):
     """The same native run with the ranks in SEPARATE processes (one slab each; here all on the one GPU, gloo as transport): the
-    library drives the whole trajectory and calls back for the hypercube slab exchange (RydProblem.shard_exchange)."""
+    library drives the whole trajectory and calls back for the hypercube slab exchange (RydProblem.shard_exchange).  Variant 14: wide
+    tiles (k_chain_wide) reading the RECEIVED partner slabs — the shape of BASELINE config 5's ranks (21-qubit slabs) in small."""
     import socket
 
     import torch.multiprocessing as mp
@@ -214,7 +218,7 @@ def test_native_sharded_run_over_processes(cuda_device, n_qubits, g):
         port = sck.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, n_qubits, g, 700 + n_qubits, q)) for r in range(world)]
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, n_qubits, g, 700 + n_qubits, q, "gloo", variant)) for r in range(world)]
     for p_ in procs:
         p_.start()
     results = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
@@ -235,13 +239,16 @@ def test_native_sharded_run_over_processes(cuda_device, n_qubits, g):
         assert r[3] == ("chained-tiles" if n_qubits - g > 12 else "direct")
 
 
-def _grad_worker(rank, world, port, n_qubits, g, seed, out_q, backend="gloo"):
+def _grad_worker(rank, world, port, n_qubits, g, seed, out_q, backend="gloo", variant=0):
     import datetime
     import os
 
     import torch.distributed as dist
 
+    from pulser_diff_amd import _native
     from pulser_diff_amd.sharded import grad_distributed_native
+
+    _native.set_kernel_variant(variant)
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     if backend == "nccl":
@@ -264,8 +271,8 @@ def _grad_worker(rank, world, port, n_qubits, g, seed, out_q, backend="gloo"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_qubits,g", [(9, 1), (15, 2)])
-def test_native_sharded_gradients_over_processes(cuda_device, n_qubits, g):
+@pytest.mark.parametrize("n_qubits,g,variant", [(9, 1, 0), (15, 2, 0), (15, 1, 14)])
+def test_native_sharded_gradients_over_processes(cuda_device, n_qubits, g, variant):
     """The native reverse sweep with the ranks in SEPARATE processes (one slab each, all on the one GPU, gloo as transport): state
     and cotangent slabs go through the exchange callback, the gradient arrays are all-reduced once; every rank must end with the
     single-GPU adjoint's gradients and its own slab of dL/dpsi0."""
@@ -280,7 +287,7 @@ def test_native_sharded_gradients_over_processes(cuda_device, n_qubits, g):
         port = sck.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, n_qubits, g, 800 + n_qubits, q)) for r in range(world)]
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, n_qubits, g, 800 + n_qubits, q, "gloo", variant)) for r in range(world)]
     for p_ in procs:
         p_.start()
     try:
