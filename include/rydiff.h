@@ -118,9 +118,9 @@ typedef struct RydProblem {
      *  10 chained passes with trajectory-per-XCD placement forced (L2-resident trajectories)
      *  11 automatic, but TWO tile layouts up to 24 qubits (32- / 16-byte runs in the second layout at 23 / 24 qubits)
      *  12 automatic, but tiles in plain workgroup order (no line-sharing swizzle where a layout's runs are shorter than 128 bytes)
-     *  13 automatic, but 2^12-amplitude tiles everywhere (automatic takes 2^13-amplitude "wide" tiles, two layouts, at 21..24
-     *     qubits: k_chain_wide)
-     *  14 chained passes with wide tiles wherever they are legal (14 <= N <= 28; three layouts from 25)
+     *  13 automatic, but 2^12-amplitude tiles everywhere (automatic takes 2^13-amplitude "wide" tiles — k_chain_wide, DESIGN.md
+     *     section 3 — with two layouts at 21..24 qubits and with three at 29 and 30, where variant 13 falls back to the direct kernels)
+     *  14 chained passes with wide tiles wherever they are legal (14 <= N <= 30; three layouts from 25)
      * "automatic" takes the one-launch sweeps up to 12 qubits, the direct kernels while few tiles are in flight
      * (B * 2^N <= 2^18, with gradients 2^19) and the chained passes beyond.  Results do not depend on the variant beyond rounding. */
     int32_t kernel_variant;

@@ -1068,8 +1068,8 @@ ChainGeom chain_geom(const Runtime& rt, bool bwd) {
     const int N = rt.pl.NL;
     int lt = kTileBits;
     if (rt.tile_mode == 13) lt = N > kWideTileBits ? kWideTileBits : kTileBits;
-    else if (rt.tile_mode == 0 && rt.variant == 0 && !rt.force_three && !rt.force_xcd && N >= 21 && N <= 24)
-        lt = kWideTileBits;
+    else if (rt.tile_mode == 0 && rt.variant == 0 && !rt.force_three && !rt.force_xcd && ((N >= 21 && N <= 24) || N >= 29))
+        lt = kWideTileBits;  // (29, 30 qubits: three layouts of wide tiles keep runs of 512 / 256 bytes in the third; 2^12 tiles end at 28)
     ChainGeom g{lt, 2};
     if (lt == kWideTileBits) g.layouts = N <= 24 ? 2 : 3;
     else if (rt.force_three == 2 && N <= 24) g.layouts = 2;
@@ -1322,7 +1322,7 @@ int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_
     } else {
         HIP_TRY(hipMemsetAsync(udiag, 0, pl.dim * sizeof(double), stream));
     }
-    if (pl.NL > kTileBits && pl.NL <= 28) {  // split diagonal for the tile layouts of the chained passes
+    if (pl.NL > kTileBits && pl.NL <= 30) {  // split diagonal for the tile layouts of the chained passes
         // (sharded runs: the layouts of the NL slab qubits, rows for every tile of the WHOLE register — rank bits on top)
         // one table set per tile size in use (the forward and the adjoint chains choose theirs independently: chain_geom)
         bool built[2] = {false, false};
@@ -1501,7 +1501,7 @@ bool chain_enabled(const Runtime& rt) {
     const int N = rt.pl.NL;
     if (rt.variant == 1 || rt.pl.n_pair) return false;  // pair terms: direct kernels
     if (rt.pl.shard_bits) return N > kTileBits && N <= 22;  // sharded: the two-layout chain on the slab qubits
-    return N > kTileBits && N <= 28 && !rt.prefer_direct;
+    return N > kTileBits && N <= (chain_geom(rt, false).lt == kWideTileBits ? 30 : 28) && !rt.prefer_direct;
 }
 
 struct ChainStep {
