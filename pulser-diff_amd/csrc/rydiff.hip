@@ -1500,7 +1500,7 @@ uint32_t to_tile_mask(const LayoutDesc& d, int lt, uint32_t index_mask) {
 bool chain_enabled(const Runtime& rt) {
     const int N = rt.pl.NL;
     if (rt.variant == 1 || rt.pl.n_pair) return false;  // pair terms: direct kernels
-    if (rt.pl.shard_bits) return N > kTileBits && N <= 22;  // sharded: the two-layout chain on the slab qubits
+    if (rt.pl.shard_bits) return N > kTileBits && chain_geom(rt, false).layouts == 2;  // sharded: two-layout chains on the slab qubits (<= 22; wide tiles: <= 24)
     return N > kTileBits && N <= (chain_geom(rt, false).lt == kWideTileBits ? 30 : 28) && !rt.prefer_direct;
 }
 

@@ -142,7 +142,7 @@ def test_native_sharded_gradients_of_a_phase_free_global_drive(cuda_device, n_qu
 
 
 @pytest.mark.parametrize("n_qubits,g,variant", [(5, 1, 0), (8, 3, 0), (12, 2, 0), (14, 1, 0), (15, 2, 0), (16, 3, 0), (17, 3, 4), (16, 2, 1), (17, 3, 14),
-                                                (24, 3, 0)])  # the last one: BASELINE config 5's own shape (8 slabs of 2^21)
+                                                (24, 3, 0), (25, 1, 0)])  # (24, 3): BASELINE config 5's own shape (8 slabs of 2^21); (25, 1): 24-qubit slabs, 64-byte runs
 def test_native_sharded_run_matches_single_gpu_solver(cuda_device, n_qubits, g, variant):
     """K6: the WHOLE sharded trajectory in one native call (RydProblem.shard_bits): slabs as trajectories, the rank qubits'
     flips read from the partner slabs, diagonal at the global index — direct kernels for slabs of <= 12 qubits, the chained
