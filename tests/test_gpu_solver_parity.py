@@ -624,7 +624,7 @@ def test_negative_pair_interactions_stay_inside_the_design_interval(cuda_device)
     assert rel_err(states.cpu().permute(0, 2, 1).numpy(), ref.numpy()) < 1e-9
 
 
-@pytest.mark.parametrize("n_qubits,variants", [(4, (0, 1)), (8, (0, 1, 9)), (13, (1, 2, 10)), (14, (1, 4))])
+@pytest.mark.parametrize("n_qubits,variants", [(4, (0, 1)), (8, (0, 1, 9)), (13, (1, 2, 10)), (14, (1, 4, 14))])
 @pytest.mark.parametrize("tape", ["steps", "full"])
 def test_state_cotangents_at_every_save_point(cuda_device, n_qubits, variants, tape):
     """A loss on the STATES at every evaluation time (grad_states non-zero at every save point, next to expectation
@@ -675,7 +675,10 @@ def test_state_cotangents_at_every_save_point(cuda_device, n_qubits, variants, t
 
 @pytest.mark.parametrize("n_qubits,variant,with_det,batch_tables,tape,solver_name", [
     (13, 4, True, 1, "full", "KRYLOV_SE"), (14, 2, False, 1, "steps", "KRYLOV_SE"), (21, 7, True, 1, "full", "KRYLOV_SE"),
-    (14, 4, True, 3, "full", "KRYLOV_SE"), (13, 10, True, 1, "full", "KRYLOV_SE"), (13, 2, True, 1, "full", "DP5_SE")])
+    (14, 4, True, 3, "full", "KRYLOV_SE"), (13, 10, True, 1, "full", "KRYLOV_SE"), (13, 2, True, 1, "full", "DP5_SE"),
+    # wide tiles (k_chain_wide): forced at 14 / 15 qubits (per-trajectory tables, both tape modes, both solvers), automatic at 22
+    (14, 14, True, 3, "full", "KRYLOV_SE"), (15, 14, False, 1, "steps", "KRYLOV_SE"), (14, 14, True, 1, "full", "DP5_SE"),
+    (22, 0, True, 1, "full", "KRYLOV_SE")])
 def test_single_tape_read_adjoint_on_both_sides_of_its_switch(cuda_device, n_qubits, variant, with_det, batch_tables, tape, solver_name):
     """The adjoint of ONE phase-free global drive on the chained tiles reads each tape vector once and recovers <F mu, x> from the
     completed cotangent (chain_kernels.hpp, REC); a factor with |beta c| < 6e-5 keeps the exact partner-sum contraction in both of
