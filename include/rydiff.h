@@ -121,6 +121,8 @@ typedef struct RydProblem {
      *  13 automatic, but 2^12-amplitude tiles everywhere (automatic takes 2^13-amplitude "wide" tiles — k_chain_wide, DESIGN.md
      *     section 3 — with two layouts at 21..24 qubits and with three at 29 and 30, where variant 13 falls back to the direct kernels)
      *  14 chained passes with wide tiles wherever they are legal (14 <= N <= 30; three layouts from 25)
+     *  15 / 16 chained passes with tiles of 2^11 / 2^10 amplitudes where two layouts of them are legal (12 <= N <= 20 / 11 <= N <= 18;
+     *     automatic takes the 2^11 tiles around 2^19 amplitudes in flight: 256 tiles, one per CU)
      * "automatic" takes the one-launch sweeps up to 12 qubits, the direct kernels while few tiles are in flight
      * (B * 2^N <= 2^18, with gradients 2^19) and the chained passes beyond.  Results do not depend on the variant beyond rounding. */
     int32_t kernel_variant;

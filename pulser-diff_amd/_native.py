@@ -182,7 +182,7 @@ def design_polynomial(rho: float, tol: float = 1e-13, max_degree: int = 120):
 # The kernel family travels in RydProblem.kernel_variant (include/rydiff.h); the C library keeps no such state.  For the
 # A/B parity tests and tuning scripts this module holds a PER-THREAD default that ``ProblemSpec.kernel_variant = None``
 # problems pick up — two threads can therefore run different variants concurrently.
-_KNOWN_VARIANTS = (0, 1, 2, 3, 4, 7, 8, 9, 10, 11, 12, 13, 14)
+_KNOWN_VARIANTS = (0, 1, 2, 3, 4, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16)
 _tls = threading.local()
 
 

@@ -17,6 +17,7 @@
 // read consecutive 16-byte slots of a permuted 1 KiB span).
 #pragma once
 
+constexpr int kSmallTileBits = 10;  // smallest tile (tuning variants 15 / 16: 2^11 / 2^10 amplitudes per workgroup)
 constexpr int kTileBits = 12;      // k_chain: 2^12 amplitudes per workgroup (64 KiB of LDS)
 constexpr int kWideTileBits = 13;  // k_chain_wide: 2^13 amplitudes per workgroup (128 KiB of the 160 KiB LDS), 21-24 qubits
 

@@ -67,7 +67,7 @@ struct Plan {
     // workspace offsets (bytes)
     size_t off_meta_idx = 0, off_coef = 0, off_stats = 0, off_udiag = 0, off_buf0 = 0, off_buf1 = 0;
     size_t off_tape = 0, off_chain = 0, off_ge = 0, off_wtot = 0, off_members = 0, off_meta2 = 0, off_pp0 = 0, off_pp1 = 0, off_split = 0, off_ptable = 0, ptable_bytes = 0;
-    size_t split_set_doubles = 0;  // doubles per split-diagonal table set (one set per tile size)
+    size_t split_off_doubles[4] = {0, 0, 0, 0};  // where the split-diagonal table set of tile size 2^(10 + i) starts inside off_split
     size_t off_pm_begin = 0, off_pm_first = 0, off_pm_tau = 0, off_pm_nsub = 0;  // inputs of the on-device factor table build
     size_t state_bytes = 0;  // B * dim * 16
     size_t total_fwd = 0;
@@ -386,12 +386,16 @@ inline size_t carve(Plan& pl, int tape_mode, bool need_backward, int chain_slots
     pl.off_buf1 = take(pl.state_bytes);
     pl.off_pp0 = take(pl.state_bytes);  // partial vectors of the chained passes
     pl.off_pp1 = take(pl.state_bytes);
-    // split interaction diagonal for the tile layouts: utt[3][2^LT] + vr[3][tiles][16] per tile size; TWO sets (LT = 12 and 13: the
-    // forward and the adjoint chains pick their tile size independently), each sized for the larger tile and the larger row count
+    // split interaction diagonal for the tile layouts: utt[3][2^LT] + vr[3][tiles][16] per tile size; one set per tile size
+    // (LT = 10 .. 13: the forward and the adjoint chains pick their tile size independently)
     {   // (sharded runs index the table by the GLOBAL tile: 2^(N-LT) rows)
         const size_t gdim = size_t(1) << pl.N;
-        pl.split_set_doubles = 3 * (8192 + (gdim >> 12 ? (gdim >> 12) : 1) * 16);  // up to three tile layouts
-        pl.off_split = take(2 * pl.split_set_doubles * sizeof(double));
+        size_t tot = 0;
+        for (int lt = 10; lt <= 13; ++lt) {  // tile sizes 2^10 .. 2^13 amplitudes, up to three tile layouts each
+            pl.split_off_doubles[lt - 10] = tot;
+            tot += 3 * ((size_t(1) << lt) + ((gdim >> lt) ? (gdim >> lt) : 1) * 16);
+        }
+        pl.off_split = take(tot * sizeof(double));
     }
     pl.off_ptable = take(pl.ptable_bytes);
     if (pl.ptable_bytes) {

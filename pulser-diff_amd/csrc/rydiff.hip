@@ -984,7 +984,7 @@ struct ChainGeom {
 
 // split-diagonal tables of one tile size: [3 layouts][2^LT + tiles * 16] doubles; one set per tile size (plan.hpp: off_split)
 double* split_tables(const Plan& pl, char* ws, int lt) {
-    return reinterpret_cast<double*>(ws + pl.off_split) + size_t(lt - kTileBits) * pl.split_set_doubles;
+    return reinterpret_cast<double*>(ws + pl.off_split) + pl.split_off_doubles[lt - kSmallTileBits];
 }
 
 LayoutDesc chain_layout(int N, int which, const ChainGeom& g) {
@@ -1021,12 +1021,14 @@ struct Runtime {
     int flags = 0;
     bool real_amp_grad = false;  // RydProblem.real_amp_grad: dL/dIm(amp) is not wanted
     bool prefer_direct = false;  // few tiles in flight: one-amplitude-per-thread kernels instead of the chained tile passes
+    bool small_tiles = false;    // ~2^19 amplitudes in flight: chained passes on tiles of 2^11 amplitudes (256 tiles: one per CU)
     // RydProblem.kernel_variant decoded (include/rydiff.h); nothing about the kernel choice lives outside this struct
     int variant = 0;              // 0 auto | 1 direct | 2..4 chained tiles | 8 auto with LDS-tile kernels below 7 qubits
     bool generic_direct = false;  // variant 9: direct kernels without the unrolled global-drive instantiations
     bool plain_tile_order = false;  // variant 12: no line-sharing tile swizzle (ChainArgs.tile_swz)
     int force_three = 0;          // 1: variant 7, three tile layouts wherever they are legal; 2: variant 11, two layouts up to 24 qubits
     int tile_mode = 0;            // 0 automatic | 12: variant 13, 2^12-amplitude tiles everywhere | 13: variant 14, wide tiles from 14 qubits
+                                  // 11 / 10: variants 15 / 16, tiles of 2^11 / 2^10 amplitudes where two layouts are legal
     bool force_xcd = false;       // variant 10: trajectory-per-XCD placement of the chained tiles forced
     int chain_lgt = 9;            // log2(threads per tile workgroup) of explicitly chosen chained variants
     // state-sharded run: where the partner slabs arrive and who moves them (RydProblem.shard_recv / shard_exchange)
@@ -1040,13 +1042,13 @@ struct Runtime {
 // RydProblem.kernel_variant -> Runtime (include/rydiff.h lists the values)
 int decode_variant(const RydProblem* p, Runtime& rt) {
     int v = p->kernel_variant;
-    if (v < 0 || v > 14 || v == 5 || v == 6) return fail(RYDIFF_EINVAL, "kernel_variant must be 0..4 or 7..14");
+    if (v < 0 || v > 16 || v == 5 || v == 6) return fail(RYDIFF_EINVAL, "kernel_variant must be 0..4 or 7..16");
     rt.generic_direct = v == 9;
     if (v == 9) v = 1;
     rt.force_three = v == 7 ? 1 : (v == 11 ? 2 : 0);
     rt.plain_tile_order = v == 12;
-    rt.tile_mode = v == 13 ? 12 : (v == 14 ? 13 : 0);
-    if (v == 7 || v == 11 || v == 12 || v == 13 || v == 14) v = 0;
+    rt.tile_mode = v == 13 ? 12 : (v == 14 ? 13 : (v == 15 ? 11 : (v == 16 ? 10 : 0)));
+    if (v == 7 || v == 11 || v >= 12) v = 0;
     rt.force_xcd = v == 10;
     if (v == 10) v = 0;
     rt.variant = v;
@@ -1068,6 +1070,8 @@ ChainGeom chain_geom(const Runtime& rt, bool bwd) {
     const int N = rt.pl.NL;
     int lt = kTileBits;
     if (rt.tile_mode == 13) lt = N > kWideTileBits ? kWideTileBits : kTileBits;
+    else if (rt.tile_mode == 10 || rt.tile_mode == 11) lt = (N > rt.tile_mode && N <= 2 * rt.tile_mode - 2) ? rt.tile_mode : kTileBits;  // two layouts, runs >= 64 bytes
+    else if (rt.small_tiles) lt = 11;
     else if (rt.tile_mode == 0 && rt.variant == 0 && !rt.force_three && !rt.force_xcd && ((N >= 21 && N <= 24) || N >= 29))
         lt = kWideTileBits;  // (29, 30 qubits: three layouts of wide tiles keep runs of 512 / 256 bytes in the third; 2^12 tiles end at 28)
     ChainGeom g{lt, 2};
@@ -1225,9 +1229,23 @@ void fill_info(const Runtime& rt, double lo, double hi, size_t ws, RydPlanInfo* 
 // amplitudes in flight (N=13: 5.3 vs 9.4 us per pass, N=16 B=4: +13 %), and the same with gradients since the direct kernels
 // keep the full tape too and have unrolled instantiations for one global drive (N=18, 200 steps: 50 ms vs 69 ms chained; N=19:
 // 83 vs 78 ms).  Explicit kernel variants are left alone (A/B tests).
+// Around 2^19 amplitudes in flight (one 19-qubit trajectory, 2 x 18, 4 x 17, 8 x 16 ...) tiles of 2^11 amplitudes give 256 tiles — one
+// per CU — where 2^12 tiles fill half of the chip and the direct kernels move every partner through the fabric: forward pass
+// 10.8-11.1 -> 9.0 us, fwd+grad +10 ... +20 % (profiles/r03_small_tiles.txt).  Forward-only runs: the whole range (2^18, 2^19]; with
+// gradients from 7 * 2^16 amplitudes and 14 qubits on (below, the direct adjoint stays ahead).  Automatic choice only.
+bool small_tiles_win(const Runtime& rt, bool with_gradients) {
+    const Plan& pl = rt.pl;
+    if (rt.variant != 0 || rt.force_three || rt.force_xcd || rt.tile_mode != 0 || pl.shard_bits || pl.n_pair || pl.ga.flagged) return false;
+    if (pl.N < 13 || pl.N > 19) return false;
+    const size_t amps = size_t(pl.B) << pl.N;
+    if (amps > (size_t(1) << 19)) return false;
+    return with_gradients ? (amps >= (size_t(7) << 16) && pl.N >= 14) : amps > (size_t(1) << 18);
+}
+
 bool few_tiles(const Runtime& rt, bool with_gradients) {
     const Plan& pl = rt.pl;
-    if (rt.variant != 0 || rt.force_three || rt.force_xcd || rt.tile_mode == kWideTileBits || pl.shard_bits) return false;
+    if (rt.small_tiles) return false;
+    if (rt.variant != 0 || rt.force_three || rt.force_xcd || (rt.tile_mode != 0 && rt.tile_mode != kTileBits) || pl.shard_bits) return false;
     // forward only: crossover at 2^18 amplitudes in flight (N = 19: 12.5 us direct vs 10.8 us chained per pass).  With gradients the
     // direct ADJOINT pass (own tape element only, partner reads of the cotangent served by L2) stays ahead of the chained one up to
     // 2^19 (11.6-12.8 vs 14.0-14.7 us) and the pair of passes wins by 1-7 % there (profiles/r02_crossover_direct_vs_chained.txt);
@@ -1275,6 +1293,7 @@ int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_
         return fail(RYDIFF_ENOTIMPL, "state-sharded runs do not take dense pair terms");
     if (pl.shard_bits) rt.generic_direct = true;  // (the unrolled direct kernels know nothing about rank qubits)
     if (need_tape == 2 && !full_tape_possible(pl)) need_tape = 1;  // full tape only with chained passes
+    rt.small_tiles = small_tiles_win(rt, need_backward || need_tape != 0);
     rt.prefer_direct = few_tiles(rt, need_backward || need_tape != 0);
     const size_t need = carve(pl, need_tape, need_backward, std::max(rt.max_step_factors - 1, 1), rt.total_factors);
     if (workspace_bytes < need)
@@ -1325,11 +1344,11 @@ int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_
     if (pl.NL > kTileBits && pl.NL <= 30) {  // split diagonal for the tile layouts of the chained passes
         // (sharded runs: the layouts of the NL slab qubits, rows for every tile of the WHOLE register — rank bits on top)
         // one table set per tile size in use (the forward and the adjoint chains choose theirs independently: chain_geom)
-        bool built[2] = {false, false};
+        bool built[4] = {false, false, false, false};
         for (int bwd = 0; bwd <= (need_backward ? 1 : 0); ++bwd) {
             const ChainGeom g = chain_geom(rt, bwd != 0);
-            if (built[g.lt - kTileBits]) continue;
-            built[g.lt - kTileBits] = true;
+            if (built[g.lt - kSmallTileBits]) continue;
+            built[g.lt - kSmallTileBits] = true;
             const unsigned tiles = unsigned((size_t(1) << pl.N) >> g.lt);
             const size_t tile_amps = size_t(1) << g.lt;
             double* split = split_tables(pl, ws, g.lt);
@@ -1533,7 +1552,7 @@ struct ChainStep {
 
 template <int LT, int LGT, bool CPLX, bool BWD, bool FAST = false, bool RES = false>
 int launch_chain_t(const ChainArgs& ca, unsigned tiles, hipStream_t stream) {
-    static_assert(LT == kTileBits || (LT == kWideTileBits && LGT == 10 && !RES), "wide tiles: 1024 threads, no L2-resident placement");
+    static_assert(LT == kTileBits || (LT >= kSmallTileBits && LT <= kWideTileBits && LGT == 10 && !RES), "other tile sizes: 1024 threads, no L2-resident placement");
     if constexpr (!FAST) {  // one global drive, at most one detuning group: the loop-free instantiation
         if (ca.ga == 1 && ca.gd <= 1 && ca.sta_mask[0] == (1u << LT) - 1u)
             return launch_chain_t<LT, LGT, CPLX, BWD, true, RES>(ca, tiles, stream);
@@ -1678,6 +1697,8 @@ int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, const BatchSl
     // (the real-drive adjoint, without the signed sums, fits 1024 threads too: measured 2710 -> 2767 steps/s on C3)
     const int lgt = rt.variant == 0 ? ((cs.bwd && cplx) ? 9 : 10) : rt.chain_lgt;
     if (geom.lt == kWideTileBits) return launch_chain_l<kWideTileBits, 10>(ca, tiles, cplx, cs.bwd, stream);
+    if (geom.lt == 11) return launch_chain_l<11, 10>(ca, tiles, cplx, cs.bwd, stream);
+    if (geom.lt == 10) return launch_chain_l<10, 10>(ca, tiles, cplx, cs.bwd, stream);
     if (bs.xcd)  // L2-resident placement (automatic thread counts only: variant 10 decodes to 0)
         return lgt == 9 ? launch_chain_l<kTileBits, 9, true>(ca, tiles, cplx, cs.bwd, stream) : launch_chain_l<kTileBits, 10, true>(ca, tiles, cplx, cs.bwd, stream);
     switch (lgt) {
@@ -2046,8 +2067,8 @@ void describe_kernels(const Runtime& rt, const RydProblem* p, bool backward, Ryd
                 std::snprintf(bwd ? info->kernel_bwd : info->kernel_fwd, sizeof(info->kernel_fwd), "k_chain_wide<%d,%s,%s,%s>", kWideTileBits,
                               b(cplx), b(bwd != 0), b(fast));
             else
-                std::snprintf(bwd ? info->kernel_bwd : info->kernel_fwd, sizeof(info->kernel_fwd), "k_chain<%d,%d,%s,%s,%s,%s>", kTileBits, lgt,
-                              b(cplx), b(bwd != 0), b(fast), b(res));
+                std::snprintf(bwd ? info->kernel_bwd : info->kernel_fwd, sizeof(info->kernel_fwd), "k_chain<%d,%d,%s,%s,%s,%s>", chain_geom(rt, bwd != 0).lt,
+                              chain_geom(rt, bwd != 0).lt == kTileBits ? lgt : 10, b(cplx), b(bwd != 0), b(fast), b(res));
         }
     } else if (info->kernel_family == 2) {
         if (direct_global_ok(rt)) {
@@ -2118,6 +2139,7 @@ int rydiff_plan(const RydProblem* p, int need_tape, int need_backward, void* scr
     const size_t ws = carve(rt.pl, tm, need_backward != 0, std::max(rt.max_step_factors - 1, 1), rt.total_factors);
     fill_info(rt, lo, hi, ws, info);
     info->tape_mode = tm;
+    rt.small_tiles = small_tiles_win(rt, need_backward != 0 || tm != 0);
     rt.prefer_direct = few_tiles(rt, need_backward != 0 || tm != 0);
     if (persist_enabled(rt)) info->kernel_family = lanes_enabled(rt.variant, rt.pl.N, rt.pl.ga.n, rt.pl.gd.n, rt.pl.n_pair) ? 0 : 1;
     else info->kernel_family = chain_enabled(rt) ? 3 : 2;

@@ -251,7 +251,10 @@ def _run_variant(variant, terms, tsave, psi_bd, device, obs, grads=True, batch_t
                                                      # wide (2^13-amplitude) tiles: automatic at 21..24 qubits (above), forced at small and
                                                      # large sizes (14: three layouts from 25), and the 2^12 tiles kept selectable (13)
                                                      (14, True, 14), (17, False, 14), (21, False, 0), (24, True, 0), (25, True, 14), (25, False, 14),
-                                                     (22, True, 13), (23, False, 13)])
+                                                     (22, True, 13), (23, False, 13),
+                                                     # tiles of 2^11 / 2^10 amplitudes (variants 15 / 16); 2^11 is the automatic choice around 2^19
+                                                     # amplitudes in flight (one 19-qubit trajectory)
+                                                     (14, True, 16), (15, False, 15), (18, True, 16), (19, True, 0), (19, False, 15), (20, True, 15)])
 def test_chained_tile_kernels_match_direct_kernels(cuda_device, n_qubits, local, variant):
     """A/B on the GPU: the chained LDS-tile kernels (two tile layouts up to 22 qubits, three from 23 — variant 7 forces
     three wherever legal, variant 11 two up to 24 qubits; where a layout's runs are shorter than a 128-byte line the tiles that

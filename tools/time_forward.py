@@ -3,6 +3,8 @@ import sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch
+import gc
+gc.collect(); gc.freeze()  # keep CPython's generation-2 collections (~35 ms over torch's objects) out of the timing windows
 from pulser_diff_amd.solver import ProblemSpec, SolverType, evolve
 from pulser_diff_amd import _native
 import os

@@ -5,6 +5,8 @@ from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch
+import gc
+gc.collect(); gc.freeze()  # keep CPython's generation-2 collections (~35 ms over torch's objects) out of the timing windows
 
 import os
 import time
