@@ -181,6 +181,12 @@ typedef struct RydProblem {
      * pulse inside one sample interval) wants a finer step than the smooth pieces — a caller that builds the tables on the host
      * knows where that is (pulser-diff_amd/hamiltonian.py: piece_refinement) and the library does not have to read them back. */
     const uint8_t* dp5_piece_refine;
+
+    /* need_tape = 3 (PARTIAL tape) only: the number of TRAILING tsave intervals whose factor outputs are all kept in the workspace
+     * tape (1 .. n_tsave - 1); the earlier intervals keep their save-point states only and are recomputed by the adjoint sweep.  The
+     * caller sizes it to the HBM that is free (rydiff_plan reports the workspace for the value given): what the full tape of
+     * need_tape = 2 does for a run that fits, this does for the part of a run that fits. */
+    int32_t tape_steps;
 } RydProblem;
 
 /* Result of rydiff_plan(): everything that depends on the VALUES in the coefficient tables. */
@@ -193,8 +199,9 @@ typedef struct RydPlanInfo {
     int32_t flags;                   /* bit 0: some flip coefficient has a non-zero imaginary part */
     int64_t total_factors;           /* factor passes of one forward run = H applications per trajectory */
     size_t workspace_bytes;          /* device workspace needed by forward/backward for the flags given to rydiff_plan */
-    int32_t tape_mode;               /* the tape the workspace was sized for: 0 none, 1 one state per tsave, 2 full (need_tape = 2
-                                        is granted only where the chained tile passes will run) */
+    int32_t tape_mode;               /* the tape the workspace was sized for: 0 none, 1 one state per tsave, 2 full, 3 partial (one state per
+                                        tsave + every factor output of the last RydProblem.tape_steps intervals); need_tape = 2 / 3 are granted
+                                        from 12 / 13 qubits on and without pair terms, otherwise downgraded to 1 */
     int32_t kernel_family;           /* which forward kernels the problem will run on (reporting only): 0 one-wave lane sweep
                                         (<= 6 qubits), 1 one-workgroup persistent sweep (<= 12 qubits), 2 direct launch per factor,
                                         3 chained LDS-tile launch per factor */
@@ -214,6 +221,11 @@ typedef struct RydPlanInfo {
  *                        sweep recomputes nothing.  Sized for 288 GB of HBM: 156 GiB at N=20, T=1000.  Granted from 12
  *                        qubits on and without pair terms (below, the adjoint sweep is one launch and recomputes on chip);
  *                        otherwise falls back to 1.  RydPlanInfo.tape_mode reports what was granted.
+ *                  3: PARTIAL tape — one state per tsave plus the output of every factor pass of the LAST RydProblem.tape_steps
+ *                        tsave intervals: the adjoint sweep recomputes the earlier intervals only.  For runs whose full tape does
+ *                        not fit (22 qubits x 600 steps, a batch of two 20-qubit trajectories x 1000 steps ...): the caller sizes
+ *                        tape_steps to the free HBM.  Granted from 13 qubits on, without pair terms, not for state-sharded runs;
+ *                        otherwise falls back to 1.
  *   need_backward  != 0: reserve the backward-sweep buffers too
  *   scratch        DEVICE, >= RYDIFF_PLAN_SCRATCH_BYTES */
 int rydiff_plan(const RydProblem* p, int need_tape, int need_backward, void* scratch, void* stream, RydPlanInfo* info);
@@ -225,8 +237,8 @@ int rydiff_plan(const RydProblem* p, int need_tape, int need_backward, void* scr
  *               RYDIFF_EWORKSPACE)
  *   psi0        DEVICE complex128 [B][2^N]
  *   states_out  DEVICE complex128 [n_tsave][B][2^N], or NULL (trajectory kept in the workspace tape if need_tape).
- *               With need_tape = 2 AND states_out the factor outputs go to the (granted) full tape and the states at the
- *               save points are copied out of it — stored states plus a later gradient without recomputation.
+ *               With need_tape = 2 / 3 AND states_out the factor outputs go to the (granted) workspace tape and the states at the
+ *               save points are copied out of it — stored states plus a later gradient without (or with less) recomputation.
  *   expect_out  DEVICE float64 [n_obs][n_tsave][B], or NULL */
 int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi0, void* states_out, double* expect_out,
                    void* workspace, size_t workspace_bytes, int need_tape, void* stream);
@@ -235,8 +247,8 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
  * sub-step (derivative.py:40,76).  Cotangents use torch's convention for complex tensors
  * (grad = dL/dRe + i dL/dIm).  The workspace must be the one the forward call used when the
  * trajectory lives in its tape (states == NULL).
- *   states       DEVICE: the states_out of the forward call, or NULL to use the workspace tape (with need_tape = 2 the
- *                granted full workspace tape is used even when states is given)
+ *   states       DEVICE: the states_out of the forward call, or NULL to use the workspace tape (with need_tape = 2 / 3 the
+ *                granted workspace tape is used even when states is given)
  *   grad_states  DEVICE complex128 [n_tsave][B][2^N] or NULL
  *   grad_expect  DEVICE float64 [n_obs][n_tsave][B] or NULL
  *   g_amp        DEVICE complex128 [coeff_batch][n_amp_terms][n_samples] or NULL   (overwritten)

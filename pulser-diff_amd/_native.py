@@ -63,6 +63,7 @@ class RydProblem(ctypes.Structure):
         ("amp_conditioned_terms", ctypes.c_uint64),
         ("det_ones_terms", ctypes.c_uint64),
         ("dp5_piece_refine", ctypes.c_void_p),
+        ("tape_steps", ctypes.c_int32),
     ]
 
 

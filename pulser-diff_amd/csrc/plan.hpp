@@ -366,8 +366,9 @@ inline bool build_plan(const RydProblem* p, Plan& pl, std::string& err, double w
 
 // Carve the workspace. `chain_slots` = number of intermediate state buffers the backward recompute needs.
 // tape_mode: 0 none | 1 one state per tsave | 2 FULL: the output of every factor pass (no recompute in the adjoint sweep;
-// needs total_factors+1 states of HBM — e.g. 156 GiB for N=20, T=1000, which an MI355X's 288 GB holds)
-inline size_t carve(Plan& pl, int tape_mode, bool need_backward, int chain_slots, int64_t total_factors = 0) {
+// needs total_factors+1 states of HBM — e.g. 156 GiB for N=20, T=1000, which an MI355X's 288 GB holds) | 3 PARTIAL: one state per
+// tsave + the intermediate factor outputs of the trailing intervals (`tape_entries` states in all, counted by the caller)
+inline size_t carve(Plan& pl, int tape_mode, bool need_backward, int chain_slots, int64_t total_factors = 0, int64_t tape_entries = 0) {
     // factor table of the persistent small-N kernel: 40 bytes per factor pass
     pl.ptable_bytes = (pl.N <= 12 && !pl.shard_bits) ? size_t(total_factors) * 48 + 64 : 0;  // sizeof(PersistFactor)
     const size_t E = pl.stages.size();
@@ -408,6 +409,7 @@ inline size_t carve(Plan& pl, int tape_mode, bool need_backward, int chain_slots
     pl.total_fwd = off;
     pl.tape_mode = tape_mode;
     if (tape_mode == 2) pl.off_tape = take(size_t(total_factors + 1) * pl.state_bytes);
+    else if (tape_mode == 3) pl.off_tape = take(size_t(tape_entries) * pl.state_bytes);
     else pl.off_tape = tape_mode ? take(size_t(pl.T + 1) * pl.state_bytes) : 0;
     pl.chain_slots = chain_slots;
     if (need_backward) {

@@ -1263,6 +1263,36 @@ bool full_tape_possible(const Plan& pl) {
     return pl.n_pair == 0;
 }
 
+// PARTIAL tape (need_tape = 3, RydProblem.tape_steps = K): region A = one state per tsave (T + 1 entries, as tape mode 1), region B = the
+// intermediate factor outputs (every factor output that is not a step's last) of the LAST K tsave intervals, in run order.  The adjoint
+// sweep recomputes the factor inputs of the earlier intervals only.  What the full tape is to a run that fits in HBM, this is to the
+// part of a run that fits.  Launch-per-factor sweeps only (13 qubits and up; no pair terms, not sharded).
+bool partial_tape_possible(const Runtime& rt) {
+    return full_tape_possible(rt.pl) && rt.pl.N > kTileBits;
+}
+
+int64_t step_factor_count(const Runtime& rt, int k) {
+    int64_t f = 0;
+    for (int e = rt.pl.step_begin[k]; e < rt.pl.step_begin[k + 1]; ++e) f += int64_t(rt.pl.stages[e].nsub) * rt.poly.degree;
+    return f;
+}
+
+struct TapeMap {
+    int k0 = 0;                     // first tsave interval whose intermediate factor outputs are on the tape
+    std::vector<int64_t> bprefix;   // [T + 1]: region-B entries before interval k (0 up to k0)
+    int64_t entries = 0;            // region A + region B
+};
+
+TapeMap partial_tape_map(const Runtime& rt, int tape_steps) {
+    const Plan& pl = rt.pl;
+    TapeMap m;
+    m.k0 = std::max(0, pl.T - std::max(tape_steps, 0));
+    m.bprefix.assign(pl.T + 1, 0);
+    for (int k = 0; k < pl.T; ++k) m.bprefix[k + 1] = m.bprefix[k] + (k >= m.k0 ? std::max<int64_t>(step_factor_count(rt, k) - 1, 0) : 0);
+    m.entries = int64_t(pl.T + 1) + m.bprefix[pl.T];
+    return m;
+}
+
 // common prologue of forward / backward: plan, (optional) stats, carve, upload metadata, expand coefficients, udiag.
 // With `info` given nothing in here waits for the device.
 int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_t workspace_bytes, int need_tape,
@@ -1293,9 +1323,11 @@ int prepare(const RydProblem* p, const RydPlanInfo* info, void* workspace, size_
         return fail(RYDIFF_ENOTIMPL, "state-sharded runs do not take dense pair terms");
     if (pl.shard_bits) rt.generic_direct = true;  // (the unrolled direct kernels know nothing about rank qubits)
     if (need_tape == 2 && !full_tape_possible(pl)) need_tape = 1;  // full tape only with chained passes
+    if (need_tape == 3 && (!partial_tape_possible(rt) || p->tape_steps < 1)) need_tape = 1;
     rt.small_tiles = small_tiles_win(rt, need_backward || need_tape != 0);
     rt.prefer_direct = few_tiles(rt, need_backward || need_tape != 0);
-    const size_t need = carve(pl, need_tape, need_backward, std::max(rt.max_step_factors - 1, 1), rt.total_factors);
+    const size_t need = carve(pl, need_tape, need_backward, std::max(rt.max_step_factors - 1, 1), rt.total_factors,
+                              need_tape == 3 ? partial_tape_map(rt, p->tape_steps).entries : 0);
     if (workspace_bytes < need)
         return fail(RYDIFF_EWORKSPACE, "workspace too small: need " + std::to_string(need) + " bytes, got " + std::to_string(workspace_bytes));
     char* ws = static_cast<char*>(workspace);
@@ -2135,8 +2167,11 @@ int rydiff_plan(const RydProblem* p, int need_tape, int need_backward, void* scr
     rc = finish_runtime(rt, lo, hi);
     if (rc) return rc;
     int tm = need_tape;
+    if (tm < 0 || tm > 3) return fail(RYDIFF_EINVAL, "need_tape must be 0..3");
     if (tm == 2 && !full_tape_possible(rt.pl)) tm = 1;
-    const size_t ws = carve(rt.pl, tm, need_backward != 0, std::max(rt.max_step_factors - 1, 1), rt.total_factors);
+    if (tm == 3 && (!partial_tape_possible(rt) || p->tape_steps < 1)) tm = 1;
+    const size_t ws = carve(rt.pl, tm, need_backward != 0, std::max(rt.max_step_factors - 1, 1), rt.total_factors,
+                            tm == 3 ? partial_tape_map(rt, p->tape_steps).entries : 0);
     fill_info(rt, lo, hi, ws, info);
     info->tape_mode = tm;
     rt.small_tiles = small_tiles_win(rt, need_backward != 0 || tm != 0);
@@ -2154,13 +2189,15 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
     Runtime rt;
     // need_tape = 2 together with states_out: the caller wants the stored states AND a gradient later — where the full tape is
     // granted the factor outputs go to the workspace tape and the states at the save points are copied out of it
-    int rc = prepare(p, info, workspace, workspace_bytes, need_tape == 2 ? 2 : (states_out ? 0 : need_tape), false, stream, rt);
+    int rc = prepare(p, info, workspace, workspace_bytes, need_tape >= 2 ? need_tape : (states_out ? 0 : need_tape), false, stream, rt);
     if (rc) return rc;
     const Plan& pl = rt.pl;
     char* ws = static_cast<char*>(workspace);
     const size_t sv = size_t(pl.B) * pl.dim;  // complex elements per saved state
     double2* buf[2] = {reinterpret_cast<double2*>(ws + pl.off_buf0), reinterpret_cast<double2*>(ws + pl.off_buf1)};
     const bool full_ws_tape = pl.tape_mode == 2;  // (prepare downgrades the request where the full tape is not possible)
+    const bool partial_tape = pl.tape_mode == 3;  // save-point states + the factor outputs of the trailing intervals, both in the workspace
+    const TapeMap tmap = partial_tape ? partial_tape_map(rt, p->tape_steps) : TapeMap{};
     double2* sout = static_cast<double2*>(states_out);
     // final_state_only: no per-step states; the state at the last evaluation time is copied to states_out at the end
     double2* final_dst = nullptr;
@@ -2171,8 +2208,9 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
         sout = nullptr;
         states_out = nullptr;
     }
-    double2* tape = (states_out && !full_ws_tape) ? sout : (pl.tape_mode ? reinterpret_cast<double2*>(ws + pl.off_tape) : nullptr);
-    double2* copy_out = (states_out && full_ws_tape) ? sout : nullptr;  // states at the save points, copied from the full tape
+    double2* tape = (states_out && !full_ws_tape && !partial_tape) ? sout : (pl.tape_mode ? reinterpret_cast<double2*>(ws + pl.off_tape) : nullptr);
+    double2* copy_out = (states_out && (full_ws_tape || partial_tape)) ? sout : nullptr;  // states at the save points, copied from the workspace tape
+    double2* tape_b = partial_tape ? tape + size_t(pl.T + 1) * sv : nullptr;  // region B of the partial tape
     const double2* cur = static_cast<const double2*>(psi0);
     if (tape) {
         HIP_TRY(hipMemcpyAsync(tape, psi0, pl.state_bytes, hipMemcpyDeviceToDevice, stream));
@@ -2226,11 +2264,13 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
         // one chain over the whole run: factor i of step k; complete outputs at step ends go to the tape
         std::vector<ChainItem> all;
         std::vector<int> step_of_end;  // for factor i: k+1 if it ends step k, else 0
+        std::vector<int64_t> b_entry;  // partial tape: region-B entry of factor i's output, -1: not kept
         for (int k = 0; k < pl.T; ++k) {
             build_step_chain(rt, k, chain);
             for (size_t i = 0; i < chain.size(); ++i) {
                 all.push_back(chain[i]);
                 step_of_end.push_back(i + 1 == chain.size() ? k + 1 : 0);
+                if (partial_tape) b_entry.push_back((k >= tmap.k0 && i + 1 < chain.size()) ? tmap.bprefix[k] + int64_t(i) : -1);
             }
         }
         const bool full_tape = full_ws_tape;
@@ -2241,6 +2281,7 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
             auto dst = [&](int i) -> double2* {
                 if (full_tape) return tape + size_t(i + 1) * sv;  // entry g = output of global factor g (entry 0 = psi0)
                 if (step_of_end[i] && tape) return tape + size_t(step_of_end[i]) * sv;
+                if (partial_tape && b_entry[i] >= 0) return tape_b + size_t(b_entry[i]) * sv;
                 if (bs.xcd) return buf[0];  // rewritten in place: the trajectory's lines stay in its XCD's L2
                 flip ^= 1;
                 return buf[flip];
@@ -2278,6 +2319,7 @@ int rydiff_forward(const RydProblem* p, const RydPlanInfo* info, const void* psi
             double2* dst;
             if (full_tape_direct) dst = tape + (gfac + 1) * sv;
             else if (last && tape) dst = tape + size_t(k + 1) * sv;
+            else if (partial_tape && k >= tmap.k0) dst = tape_b + size_t(tmap.bprefix[k] + int64_t(i)) * sv;
             else {
                 dst = buf[pp];
                 if (dst == cur) dst = buf[pp ^ 1];
@@ -2309,7 +2351,7 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!states && !need_tape) return fail(RYDIFF_EINVAL, "backward needs the trajectory: pass states or use the workspace tape");
     Runtime rt;
-    int rc = prepare(p, info, workspace, workspace_bytes, need_tape == 2 ? 2 : (states ? 0 : need_tape), true, stream, rt);
+    int rc = prepare(p, info, workspace, workspace_bytes, need_tape >= 2 ? need_tape : (states ? 0 : need_tape), true, stream, rt);
     if (rc) return rc;
     const Plan& pl = rt.pl;
     char* ws = static_cast<char*>(workspace);
@@ -2317,7 +2359,7 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
     const size_t E = pl.stages.size();
     if (!states && !pl.tape_mode) return fail(RYDIFF_EINVAL, "backward needs the trajectory: pass states or use the workspace tape");
     // the full workspace tape (written by a forward call with need_tape = 2) is preferred over `states`
-    const double2* tape = (pl.tape_mode == 2 || !states) ? reinterpret_cast<const double2*>(ws + pl.off_tape) : static_cast<const double2*>(states);
+    const double2* tape = (pl.tape_mode >= 2 || !states) ? reinterpret_cast<const double2*>(ws + pl.off_tape) : static_cast<const double2*>(states);
     double2* lam[2] = {reinterpret_cast<double2*>(ws + pl.off_buf0), reinterpret_cast<double2*>(ws + pl.off_buf1)};
     double2* chainbuf = reinterpret_cast<double2*>(ws + pl.off_chain);
     double* ge = reinterpret_cast<double*>(ws + pl.off_ge);
@@ -2347,6 +2389,10 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
     int cl = 0;
     // where the state at tsave[k] lives: one entry per tsave, or (full tape) one entry per factor pass
     const bool full_tape = pl.tape_mode == 2;
+    const bool partial_tape = pl.tape_mode == 3;
+    const TapeMap tmap = partial_tape ? partial_tape_map(rt, p->tape_steps) : TapeMap{};
+    const double2* tape_b = partial_tape ? tape + size_t(pl.T + 1) * sv : nullptr;
+    auto taped = [&](int k) { return full_tape || (partial_tape && k >= tmap.k0); };  // every factor input of interval k is on the tape
     std::vector<int64_t> fprefix(pl.T + 1, 0);
     for (int k = 0; k < pl.T; ++k) {
         int64_t f = 0;
@@ -2451,9 +2497,10 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
             // With every factor input on the tape, consecutive intervals run as ONE chain: the launch that finishes the adjoint
             // of interval k's first factor (and adds the cotangent injected at save point k) also starts interval k-1's last one.
             const int k_hi = k;
-            if (full_tape && chained) {
-                while (k > 0 && fprefix[k_hi + 1] - fprefix[k - 1] < (int64_t(1) << 16)) --k;
+            if (taped(k_hi) && chained) {
+                while (k > 0 && taped(k - 1) && fprefix[k_hi + 1] - fprefix[k - 1] < (int64_t(1) << 16)) --k;
             }
+            const bool on_tape = taped(k_hi);  // (then every interval of the merged chain is)
             chain.clear();
             save_k.clear();
             for (int kk = k; kk <= k_hi; ++kk) {
@@ -2462,12 +2509,18 @@ int rydiff_backward(const RydProblem* p, const RydPlanInfo* info, const void* st
                 chain.insert(chain.end(), part.begin(), part.end());
             }
             const int M = int(chain.size());
-            if (!full_tape && M - 1 > pl.chain_slots) return fail(RYDIFF_EWORKSPACE, "internal: chain buffers too small");
+            if (!on_tape && M - 1 > pl.chain_slots) return fail(RYDIFF_EWORKSPACE, "internal: chain buffers too small");
             // the factor inputs x_0 .. x_{M-1}: on the tape, or recomputed
             xs.assign(M + 1, nullptr);
             xs[0] = state_at(k);
             if (full_tape) {
                 for (int i = 1; i < M; ++i) xs[i] = tape + size_t(fprefix[k] + i) * sv;  // every factor input is on the tape
+            } else if (on_tape) {  // partial tape: interval kk's first input is its save-point state, the others sit in region B
+                int i = 0;
+                for (int kk = k; kk <= k_hi; ++kk) {
+                    const int mk = int(fprefix[kk + 1] - fprefix[kk]);
+                    for (int j = 0; j < mk; ++j, ++i) xs[i] = j == 0 ? state_at(kk) : tape_b + size_t(tmap.bprefix[kk] + j - 1) * sv;
+                }
             } else if (chained && M > 1) {
                 for (int i = 1; i < M; ++i) xs[i] = chainbuf + size_t(i - 1) * sv;
                 auto dst = [&](int i) -> double2* { return chainbuf + size_t(i) * sv; };

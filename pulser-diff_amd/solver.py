@@ -49,7 +49,11 @@ class ProblemSpec:
     solver: SolverType = SolverType.KRYLOV_SE
     tol: float = 0.0
     store_states: bool = True
-    tape: str = "auto"  # with store_states=False and gradients: "steps" | "full" | "auto" (full when it fits in HBM)
+    # gradients: "steps" (one state per save point + recompute) | "full" (every factor output kept) | "partial" (one state per save
+    # point + every factor output of the trailing `tape_steps` intervals) | "auto" (full when it fits in HBM, else as much of the
+    # run as fits, from 13 qubits on)
+    tape: str = "auto"
+    tape_steps: Optional[int] = None  # tape="partial": trailing save intervals kept on the tape (None: as many as fit)
     options: dict = field(default_factory=dict)
     # dense two-qubit terms of the generator (include/rydiff.h): ((qubit_a, qubit_b, 4x4 complex table), ...); constants
     pair_terms: tuple = ()
@@ -171,6 +175,34 @@ def _check_shapes(spec: ProblemSpec, amp: Tensor, det: Tensor, u_pairs: Tensor, 
         raise ValueError("batch must be <= 65535 (split the columns / trajectories into several calls)")
 
 
+def _partial_tape_steps(L, call, info, spec, dev, scratch, stream, n_t: int, state_bytes: int, forced: Optional[int]) -> int:
+    """Plan a PARTIAL tape (rydiff.h: need_tape = 3): the trailing save intervals whose factor outputs all stay in HBM.  `forced`
+    = the caller's number; None: as many as fit in 80 % of the free + reusable device memory next to the save-point states, the
+    backward buffers and (for stored states) the states output.  Leaves the plan for need_tape = 3 in `info` and the count in
+    call.problem.tape_steps and returns it; 0 (and an untouched tape_steps) when not even one interval fits or the library would
+    not grant the mode."""
+    n_steps = n_t - 1
+    if forced is not None:
+        steps = max(1, min(int(forced), n_steps))
+    else:
+        probe = _native.RydPlanInfo()
+        call.problem.tape_steps = 0
+        _native.check(L.rydiff_plan(ctypes.byref(call.problem), 1, 1, _ptr(scratch), stream, ctypes.byref(probe)))
+        free_bytes, _total = torch.cuda.mem_get_info(dev)
+        reusable = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+        budget = 0.8 * (free_bytes + reusable) - probe.workspace_bytes - (n_t * state_bytes if spec.store_states else 0)
+        per_step = max(probe.total_factors / max(n_steps, 1) - 1.0, 1.0) * state_bytes  # intermediate factor outputs of one interval
+        steps = int(min(budget // per_step, n_steps)) if budget > 0 else 0
+    if steps < 1:
+        return 0
+    call.problem.tape_steps = steps
+    _native.check(L.rydiff_plan(ctypes.byref(call.problem), 3, 1, _ptr(scratch), stream, ctypes.byref(info)))
+    if info.tape_mode != 3:
+        call.problem.tape_steps = 0
+        return 0
+    return steps
+
+
 def _stream_ptr(device: torch.device) -> ctypes.c_void_p:
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
@@ -227,7 +259,17 @@ class _RydbergEvolve(torch.autograd.Function):
                     fits = info.workspace_bytes < 0.8 * (free_bytes + reusable)
                 if fits and (need_tape or info.tape_mode == 2):
                     need_tape = 2
-            if need_tape != 2:
+                elif info.tape_mode == 2 and spec.n_qubits >= 13 and n_t > 2:
+                    # the full tape does not fit: keep the factor outputs of as many TRAILING intervals as do (need_tape = 3) — the
+                    # adjoint sweep then recomputes the earlier intervals only
+                    steps = _partial_tape_steps(L, call, info, spec, dev, scratch, stream, n_t, batch * dim * 16, None)
+                    if steps:
+                        need_tape = 3
+            if needs_grad and spec.tape == "partial":
+                steps = _partial_tape_steps(L, call, info, spec, dev, scratch, stream, n_t, batch * dim * 16, spec.tape_steps)
+                if steps:
+                    need_tape = 3
+            if need_tape < 2:
                 # a differentiated run is planned WITH the backward-sweep buffers: the backward call then reuses this plan
                 # (rydiff_plan holds the library's only stream synchronisation)
                 _native.check(L.rydiff_plan(ctypes.byref(call.problem), need_tape, int(needs_grad), _ptr(scratch),
@@ -246,8 +288,9 @@ class _RydbergEvolve(torch.autograd.Function):
                     if attempt == 0:
                         torch.cuda.synchronize(dev)
                         torch.cuda.empty_cache()
-                    elif attempt == 1 and need_tape == 2 and spec.tape != "full":
+                    elif attempt == 1 and need_tape >= 2 and spec.tape != "full":
                         need_tape = int(bool(needs_grad and not spec.store_states))
+                        call.problem.tape_steps = 0
                         _native.check(L.rydiff_plan(ctypes.byref(call.problem), need_tape, int(needs_grad), _ptr(scratch),
                                                     stream, ctypes.byref(info)))
                     else:
@@ -266,6 +309,7 @@ class _RydbergEvolve(torch.autograd.Function):
         ctx.tsave_meta = (tsave.device, tsave.dtype)
         ctx.in_dtypes = (amp.dtype, det.dtype, u_pairs.dtype, psi0.dtype)
         ctx.need_tape = need_tape
+        ctx.tape_steps = int(call.problem.tape_steps)
         ctx.keep_tape = True  # retain_graph=True callers may run backward again
         ctx.tape_workspace = workspace if need_tape else None
         ctx.save_for_backward(amp_c, det_c, u_c, psi_c, obs_c if obs_c is not None else torch.empty(0, device=dev),
@@ -274,7 +318,8 @@ class _RydbergEvolve(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.stats = {"degree": info.degree, "total_factors": info.total_factors, "rho": info.rho_design,
                      "spectral": (info.spectral_lo, info.spectral_hi), "n_stages": info.n_stages,
-                     "tape": ("none", "steps", "full")[min(need_tape, info.tape_mode) if need_tape else 0],
+                     "tape": ("none", "steps", "full", "partial")[(info.tape_mode if need_tape >= 2 else min(need_tape, info.tape_mode)) if need_tape else 0],
+                     "tape_steps": int(call.problem.tape_steps) if need_tape == 3 and info.tape_mode == 3 else 0,
                      "kernel_family": _native.KERNEL_FAMILIES[info.kernel_family],
                      "kernel_fwd": info.kernel_fwd.decode(), "kernel_bwd": info.kernel_bwd.decode()}
         spec.options["_last_stats"] = ctx.stats
@@ -291,6 +336,7 @@ class _RydbergEvolve(torch.autograd.Function):
         obs = obs_c if ctx.has_obs else None
         call = _Call(spec, amp_c, det_c, u_c, ctx.tsave_host, batch, obs, real_amp_grad=not ctx.in_dtypes[0].is_complex)
         call.problem.kernel_variant = ctx.kernel_variant  # same kernel family as the forward pass (see forward)
+        call.problem.tape_steps = ctx.tape_steps
         need = ctx.needs_input_grad
         if g_states is not None and g_states.numel() == 0:
             g_states = None

@@ -1,5 +1,5 @@
 """Forward + adjoint sweep on a small number of time steps (PMC collection / tuning helper):
-python tools/time_fwdgrad.py [N] [T] [B] [real|complex]      (RYDIFF_VARIANT selects the kernel variant)"""
+python tools/time_fwdgrad.py [N] [T] [B] [real|complex]      (RYDIFF_VARIANT selects the kernel variant, TAPE / TAPE_STEPS the tape)"""
 import sys
 from pathlib import Path
 
@@ -32,7 +32,8 @@ ts = torch.arange(T + 1, dtype=torch.float64) / 1000
 x = torch.arange(2**n, device=dev)
 zdiag = sum(1.0 - 2.0 * ((x >> j) & 1).to(torch.float64) for j in range(n))
 mask = (1 << n) - 1
-spec = ProblemSpec(n, 0.001, T + 1, (mask,), (mask,), solver=SolverType.KRYLOV_SE, store_states=False)
+spec = ProblemSpec(n, 0.001, T + 1, (mask,), (mask,), solver=SolverType.KRYLOV_SE, store_states=False,
+                   tape=os.environ.get("TAPE", "auto"), tape_steps=int(os.environ["TAPE_STEPS"]) if "TAPE_STEPS" in os.environ else None)  # TAPE=steps|full|partial|auto
 for it in range(3):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
