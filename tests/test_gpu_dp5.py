@@ -115,7 +115,8 @@ def test_time_derivative_equals_heisenberg_rate(cuda_device):
         assert abs(g[k].item() - rate.item()) < 1e-6 * max(1.0, abs(rate.item()))
 
 
-@pytest.mark.parametrize("n_qubits,tape,chained", [(13, "steps", 2), (15, "full", 2), (15, "steps", 14), (14, "full", 14)])  # 14: wide tiles
+@pytest.mark.parametrize("n_qubits,tape,chained", [(13, "steps", 2), (15, "full", 2), (15, "steps", 14), (14, "full", 14),  # 14: wide tiles
+                                                   (15, "partial", 2), (14, "partial", 1)])  # partial tape: 2 of the 4 intervals (several stages each)
 def test_continuous_solver_on_chained_tile_kernels_matches_direct_kernels(cuda_device, n_qubits, tape, chained):
     """DP5_SE on registers that take the chained LDS-tile path: several Magnus exponentials (stages) per tsave interval,
     cut at the sample grid, with either tape mode — states, expectation values and all gradients (tables, U_ij,
@@ -128,21 +129,23 @@ def test_continuous_solver_on_chained_tile_kernels_matches_direct_kernels(cuda_d
     obs = R.total_magnetization_diag(n_qubits)[None].to(cuda_device)
     w = torch.tensor([0.3, -0.2, 0.9, 0.1, 1.4], dtype=torch.float64, device=cuda_device)
     out = {}
-    for variant in (1, chained):  # chained tiles forced (one small trajectory would otherwise be routed to the direct kernels)
+    for which, variant in enumerate((1, chained)):  # chained tiles forced (one small trajectory would otherwise be routed to the direct kernels)
         _native.set_kernel_variant(variant)
         try:
             amp, det, u, spec = to_native(terms, cuda_device, SolverType.DP5_SE, store_states=False)
-            spec.tape = tape
+            spec.tape = "steps" if (tape == "partial" and which == 0) else tape  # the reference of a partial-tape run recomputes every interval
+            spec.tape_steps = 2 if spec.tape == "partial" else None
             ts = tsave0.clone().requires_grad_(True)
             for t in (amp, det, u):
                 t.requires_grad_(True)
             _, expect = evolve(amp, det, u, ts, psi0, spec, obs)
             (expect[0, :, 0] * w).sum().backward()
-            out[variant] = [expect.detach().cpu(), amp.grad.cpu(), det.grad.cpu(), u.grad.cpu(), ts.grad.cpu()]
+            out[which] = [expect.detach().cpu(), amp.grad.cpu(), det.grad.cpu(), u.grad.cpu(), ts.grad.cpu()]
             assert spec.options["_last_stats"]["n_stages"] > len(tsave0) - 1  # more than one exponential per interval
+            assert spec.options["_last_stats"]["tape"] == spec.tape
         finally:
             _native.set_kernel_variant(0)
-    for name, ref, got in zip(("expect", "amp", "det", "u", "tsave"), out[1], out[chained]):
+    for name, ref, got in zip(("expect", "amp", "det", "u", "tsave"), out[0], out[1]):
         assert rel_err(got.numpy(), ref.numpy()) < 1e-10, name
 
 
