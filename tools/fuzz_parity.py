@@ -50,17 +50,18 @@ for case in range(n_cases):
     real_tables = (not cplx) and bool(rng.integers(0, 2))  # phase-free drive handed over as a REAL tensor (RydProblem.real_amp_grad)
     if real_tables:
         amp = amp.real.contiguous()
-    tape = str(rng.choice(["auto", "steps", "full"]))
+    tape = str(rng.choice(["auto", "steps", "full", "partial"]))  # partial: the last tape_steps save intervals taped (13 qubits and up; steps below)
+    tape_steps = int(rng.integers(1, len(tsave0))) if tape == "partial" else None
     # three-level style problems (include/rydiff.h: amp_conditioned_terms / det_ones_terms): every amplitude term conditioned, the
     # detuning terms all ones-counting or all not (terms that share a qubit must agree); even registers, complex tables
     three = n % 2 == 0 and n >= 2 and not real_tables and rng.random() < 0.2
     cond = (True,) * ka if three else ()
     ones = ((bool(rng.integers(0, 2)),) * kd) if three else ()
     out = {}
-    variants = (1, 0) + ((int(rng.choice([2, 4, 10, 14])),) if n >= 13 else ())  # 10: trajectory-per-XCD placement, 14: wide tiles  # from 13 qubits also the chained tiles FORCED: auto routes small single trajectories to the direct kernels
+    variants = (1, 0) + ((int(rng.choice([2, 4, 10, 14, 15, 16])),) if n >= 13 else ())  # 10: trajectory-per-XCD placement, 14: wide tiles, 15 / 16: tiles of 2^11 / 2^10 amplitudes  # from 13 qubits also the chained tiles FORCED: auto routes small single trajectories to the direct kernels
     for variant in variants:
         _native.set_kernel_variant(variant)
-        spec = ProblemSpec(n, dt, ns, am, dm, solver=solver, store_states=store, tape=tape, amp_conditioned=cond, det_ones=ones)
+        spec = ProblemSpec(n, dt, ns, am, dm, solver=solver, store_states=store, tape=tape, tape_steps=tape_steps, amp_conditioned=cond, det_ones=ones)
         leaves = [amp.clone().requires_grad_(True), det.clone().requires_grad_(True), u.clone().requires_grad_(True),
                   tsave0.clone().requires_grad_(True), psi.clone().requires_grad_(True)]
         states, expect = evolve(*leaves, spec, obs)
@@ -81,7 +82,7 @@ for case in range(n_cases):
     worst = max(worst, e)
     flag = "" if e < 1e-9 else "   <<<<<< MISMATCH"
     fails += e >= 1e-9
-    print(f"case {case:3d}: N={n:2d} B={batch} Bc={bc} {solver.name:9s} Ka={ka} Kd={kd} cplx={int(cplx)} real={int(real_tables)} cond={int(three)} store={int(store)} tape={out[(0, 'stats')]['tape']:5s} "
+    print(f"case {case:3d}: N={n:2d} B={batch} Bc={bc} {solver.name:9s} Ka={ka} Kd={kd} cplx={int(cplx)} real={int(real_tables)} cond={int(three)} store={int(store)} tape={out[(0, 'stats')]['tape']:7s} "
           f"stages={out[(0, 'stats')]['n_stages']:3d} max rel err {e:.1e}{flag}", flush=True)
 print(f"worst {worst:.2e}; {fails} mismatches out of {n_cases}")
 sys.exit(1 if fails else 0)
