@@ -279,14 +279,15 @@ def test_chained_tile_kernels_match_direct_kernels(cuda_device, n_qubits, local,
         assert rel_err(got[key].cpu().numpy(), ref[key].cpu().numpy()) < (1e-10 if n_qubits < 21 else 1e-9), key
 
 
-def test_chained_passes_at_29_qubits_match_direct_kernels(cuda_device):
-    """29 qubits (8 GiB per vector; 2^12 tiles end at 28, the direct kernels were used beyond): three layouts of WIDE tiles, automatic,
-    against the one-amplitude-per-thread kernels — expectation values at the save points and the final state (compared on the
-    device), local channels with phases.  (Gradients through three layouts of wide tiles: the 25-qubit cases above.)"""
+@pytest.mark.parametrize("n", [29, 30])
+def test_chained_passes_at_29_and_30_qubits_match_direct_kernels(cuda_device, n):
+    """29 / 30 qubits (8 / 16 GiB per vector; 2^12 tiles end at 28, the direct kernels were used beyond): three layouts of WIDE tiles,
+    automatic, against the one-amplitude-per-thread kernels — expectation values at the save points and, at 29 qubits, the final state
+    (compared on the device); local channels with phases.  (Gradients through three layouts of wide tiles: the 25-qubit cases above.)"""
     from pulser_diff_amd import _native
     from pulser_diff_amd.solver import SolverType, evolve
 
-    n = 29
+    store = n == 29
     terms = random_terms(n, 9, 0.002, seed=229, local=True)
     tsave = torch.tensor([0.0, 0.004, 0.007], dtype=torch.float64)
     x = torch.arange(2**n, device=cuda_device)
@@ -301,20 +302,23 @@ def test_chained_passes_at_29_qubits_match_direct_kernels(cuda_device):
     for variant in (1, 0):
         _native.set_kernel_variant(variant)
         try:
-            amp, det, u, spec = to_native(terms, cuda_device, SolverType.KRYLOV_SE, store_states=True)
+            amp, det, u, spec = to_native(terms, cuda_device, SolverType.KRYLOV_SE, store_states=store)
             with torch.no_grad():
                 states, expect = evolve(amp, det, u, tsave, psi, spec, obs[None])
             torch.cuda.synchronize()
             st = spec.options["_last_stats"]
-            out[variant] = (states[-1, 0].clone(), expect.cpu().numpy(), st["kernel_family"], st.get("kernel_fwd", ""))
+            out[variant] = (states[-1, 0].clone() if store else None, expect.cpu().numpy(), st["kernel_family"], st.get("kernel_fwd", ""))
             del states, expect
             torch.cuda.empty_cache()
         finally:
             _native.set_kernel_variant(0)
     assert out[1][2] == "direct" and out[0][2] == "chained-tiles" and "k_chain_wide" in out[0][3]
     assert np.abs(out[0][1] - out[1][1]).max() < 1e-10
-    assert float((out[0][0] - out[1][0]).abs().max() / out[1][0].abs().max()) < 1e-12
-    assert abs(float(torch.linalg.vector_norm(out[0][0])) - 1.0) < 1e-12
+    z0 = 0.64 * (-n) + 0.36 * (n - 2 * bin(123456789).count("1"))  # <sum Z>(0) of psi0 = 0.8 |1...1> + 0.6i |123456789>
+    assert abs(out[0][1][0, 0, 0] - z0) < 1e-12 and abs(out[1][1][0, 0, 0] - z0) < 1e-12
+    if store:
+        assert float((out[0][0] - out[1][0]).abs().max() / out[1][0].abs().max()) < 1e-12
+        assert abs(float(torch.linalg.vector_norm(out[0][0])) - 1.0) < 1e-12
 
 
 @pytest.mark.parametrize("n_qubits,batch,store", [(13, 11, True), (14, 19, False), (16, 9, False), (17, 3, True)])
