@@ -15,6 +15,11 @@
 // Per thread: R = 2^(LT-LGT) amplitudes i = r*NT + tid, so the top LT-LGT tile bits are REGISTER bits (flips are
 // register renaming) and only the low LGT tile bits go through LDS (conflict-free ds_read_b128: consecutive lanes
 // read consecutive 16-byte slots of a permuted 1 KiB span).
+//
+// Tile sizes (a run-time property of a chain: chain_geom() in rydiff.hip; the forward and the adjoint chain choose independently):
+//   k_chain<12, 8 | 9 | 10>   2^12 amplitudes, 256 / 512 / 1024 threads: the workhorse (13..20 and 25..28 qubits, batches)
+//   k_chain<11, 10>, <10, 10>  2^11 / 2^10 amplitudes: around 2^19 amplitudes in flight (256 tiles of 2^11: one per CU); tuning variants
+//   k_chain_wide<13>           2^13 amplitudes in two register halves (below): 21..24 qubits with two layouts, 29 / 30 with three
 #pragma once
 
 constexpr int kSmallTileBits = 10;  // smallest tile (tuning variants 15 / 16: 2^11 / 2^10 amplitudes per workgroup)
