@@ -2124,7 +2124,7 @@ void describe_kernels(const Runtime& rt, const RydProblem* p, bool backward, Ryd
 extern "C" {
 
 const char* rydiff_last_error(void) { return g_last_error.c_str(); }
-const char* rydiff_version(void) { return "rydiff 0.3 (gfx950)"; }
+const char* rydiff_version(void) { return "rydiff 0.4 (gfx950)"; }
 size_t rydiff_sizeof_problem(void) { return sizeof(RydProblem); }
 size_t rydiff_sizeof_plan_info(void) { return sizeof(RydPlanInfo); }
 
