@@ -170,8 +170,8 @@ typedef struct RydProblem {
      *       2*det_k(t) * (0 - #ones) instead of 2*det_k(t) * (#zeros): on the valid codes n_g = a_i + b_i - 1, so the reference's
      *       detuning on sigma_gg (hamiltonian.py:413) is an ordinary term on the a qubits plus a ones-counting term on the b qubits.
      * All terms that address one qubit must agree on these flags; n_qubits must be even when any term is conditioned.  Such
-     * problems run on the one-launch kernels up to 12 qubits and on the generic one-amplitude-per-thread kernels beyond
-     * (forward, adjoint, every gradient). */
+     * problems run on the one-launch kernels up to 12 qubits, beyond that on the generic one-amplitude-per-thread kernels and — with
+     * enough tiles in flight, up to 20 qubits — on the chained passes over 2^12-amplitude tiles (forward, adjoint, every gradient). */
     uint64_t amp_conditioned_terms;
     uint64_t det_ones_terms;
 

@@ -72,6 +72,10 @@ struct ChainArgs {
     uint32_t sta_mask[kMaxGroups];     // per flip group: TILE-bit mask handled by the start stage
     uint32_t dmask[kMaxGroups];        // detuning groups: amplitude-INDEX masks
     int dcnt[kMaxGroups];
+    // flip groups with CONDITIONED flips (three-level registers, RydProblem.amp_conditioned_terms): the flip of a qubit acts only where its
+    // sibling qubit (amplitude-index bit ^ 1) is 1.  Needs tile layouts that keep sibling pairs together — even lo and hs: the 2^12 tiles
+    // of an even register — so that the sibling of tile bit b is tile bit b ^ 1 (k_chain only; chain_geom keeps such problems on them).
+    uint32_t cond;
     // Trajectory-per-XCD placement (speed only, results do not depend on it): workgroups are dispatched round-robin over the
     // 8 XCDs (workgroup id % 8), each XCD has its own 4 MiB L2.  With xcd_place the grid is (8 * tiles_per_traj, ceil(B/8)):
     // workgroup w of row y works on tile w / 8 of trajectory 8 y + w % 8, so that ALL tiles of one trajectory, in every
@@ -458,7 +462,8 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
             if (!mask) continue;
             double2 ts[R], ds[R];
 #ifndef RYDIFF_ABLATE_COMPUTE
-            partner_sums<LT, LGT, CPLX>(tile, uu, mask, tid, ts, ds);
+            if (!FAST && (a.cond >> g & 1u)) partner_sums<LT, LGT, CPLX, false, true>(tile, uu, mask, tid, ts, ds);
+            else partner_sums<LT, LGT, CPLX>(tile, uu, mask, tid, ts, ds);
 #else
             for (int r = 0; r < R; ++r) { ts[r] = uu[r]; ds[r] = uu[r]; }
 #endif
@@ -641,7 +646,8 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
         if (!FAST && !mask) continue;
         double2 ts[R], ds[R];
 #ifndef RYDIFF_ABLATE_COMPUTE
-        partner_sums<LT, LGT, CPLX, FAST>(tile, acc, mask, tid, ts, ds);
+        if (!FAST && (a.cond >> g & 1u)) partner_sums<LT, LGT, CPLX, false, true>(tile, acc, mask, tid, ts, ds);
+        else partner_sums<LT, LGT, CPLX, FAST>(tile, acc, mask, tid, ts, ds);
 #else
         for (int r = 0; r < R; ++r) { ts[r] = acc[r]; ds[r] = acc[r]; }
 #endif

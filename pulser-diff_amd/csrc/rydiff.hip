@@ -1069,7 +1069,8 @@ ChainGeom chain_geom(const Runtime& rt, bool bwd) {
     (void)bwd;
     const int N = rt.pl.NL;
     int lt = kTileBits;
-    if (rt.tile_mode == 13) lt = N > kWideTileBits ? kWideTileBits : kTileBits;
+    if (rt.pl.ga.flagged) lt = kTileBits;  // conditioned flips: sibling pairs must stay inside a tile (even lo and hs)
+    else if (rt.tile_mode == 13) lt = N > kWideTileBits ? kWideTileBits : kTileBits;
     else if (rt.tile_mode == 10 || rt.tile_mode == 11) lt = (N > rt.tile_mode && N <= 2 * rt.tile_mode - 2) ? rt.tile_mode : kTileBits;  // two layouts, runs >= 64 bytes
     else if (rt.small_tiles) lt = 11;
     else if (rt.tile_mode == 0 && rt.variant == 0 && !rt.force_three && !rt.force_xcd && ((N >= 21 && N <= 24) || N >= 29))
@@ -1155,9 +1156,9 @@ int finish_runtime(Runtime& rt, double lo, double hi) {
     fill_group_args(pl, rt.garg);
     if (pl.ga.flagged) {
         // conditioned flips (three-level registers): the one-launch kernels up to 12 qubits (their tile IS the register), beyond
-        // that the generic one-amplitude-per-thread kernels — never the unrolled global-drive or the chained tile kernels
+        // that the generic one-amplitude-per-thread kernels (never the unrolled global-drive ones) while few tiles are in flight and
+        // the chained passes on 2^12-amplitude tiles (sibling pairs stay inside a tile: chain_geom) beyond
         rt.generic_direct = true;
-        if (pl.N > kTileBits) rt.variant = 1;
     }
     rt.parg.n = pl.n_pair;
     for (int t = 0; t < pl.n_pair; ++t) {
@@ -1551,6 +1552,10 @@ uint32_t to_tile_mask(const LayoutDesc& d, int lt, uint32_t index_mask) {
 bool chain_enabled(const Runtime& rt) {
     const int N = rt.pl.NL;
     if (rt.variant == 1 || rt.pl.n_pair) return false;  // pair terms: direct kernels
+    // conditioned flips (three-level registers): measured (tools/time_three_level.py) the chained passes win up to 20 qubits (10 atoms:
+    // 29.6 -> 20.6 us per pass, fwd+grad +23 %); beyond, the 2^12 tiles' short runs / third layout and the 512-thread signed-sum adjoint
+    // lose to the generic direct kernels (22 qubits: 758 vs 687 steps/s fwd+grad).  Explicit chained variants still take them (tests).
+    if (rt.pl.ga.flagged && N > 20 && rt.variant == 0) return false;
     if (rt.pl.shard_bits) return N > kTileBits && chain_geom(rt, false).layouts == 2;  // sharded: two-layout chains on the slab qubits (<= 22; wide tiles: <= 24)
     return N > kTileBits && N <= (chain_geom(rt, false).lt == kWideTileBits ? 30 : 28) && !rt.prefer_direct;
 }
@@ -1586,7 +1591,7 @@ template <int LT, int LGT, bool CPLX, bool BWD, bool FAST = false, bool RES = fa
 int launch_chain_t(const ChainArgs& ca, unsigned tiles, hipStream_t stream) {
     static_assert(LT == kTileBits || (LT >= kSmallTileBits && LT <= kWideTileBits && LGT == 10 && !RES), "other tile sizes: 1024 threads, no L2-resident placement");
     if constexpr (!FAST) {  // one global drive, at most one detuning group: the loop-free instantiation
-        if (ca.ga == 1 && ca.gd <= 1 && ca.sta_mask[0] == (1u << LT) - 1u)
+        if (ca.ga == 1 && ca.gd <= 1 && ca.sta_mask[0] == (1u << LT) - 1u && !ca.cond)
             return launch_chain_t<LT, LGT, CPLX, BWD, true, RES>(ca, tiles, stream);
     }
     // tile + reduction scratch: one double per wave (forward), [4 ga + gd] slots per wave (adjoint: parked gradient partials)
@@ -1672,6 +1677,7 @@ int launch_chain(const Runtime& rt, char* ws, const ChainStep& cs, const BatchSl
     ca.write_v = cs.write_v;
     ca.ga = pl.ga.n;
     ca.gd = pl.gd.n;
+    ca.cond = pl.ga.flagged;
     ca.xcd_place = bs.xcd ? 1 : 0;
     ca.resident = bs.xcd ? 1 : 0;
     ca.b_first = bs.first;
@@ -2090,7 +2096,7 @@ void describe_kernels(const Runtime& rt, const RydProblem* p, bool backward, Ryd
     auto b = [](bool v) { return v ? "true" : "false"; };
     info->kernel_fwd[0] = info->kernel_bwd[0] = 0;
     if (info->kernel_family == 3) {
-        const bool fast = pl.ga.n == 1 && pl.gd.n <= 1 && (pl.ga.amp_index_mask[0] & ((1u << pl.NL) - 1u)) == (1u << pl.NL) - 1u;
+        const bool fast = pl.ga.n == 1 && pl.gd.n <= 1 && (pl.ga.amp_index_mask[0] & ((1u << pl.NL) - 1u)) == (1u << pl.NL) - 1u && !pl.ga.flagged;
         for (int bwd = 0; bwd <= (backward ? 1 : 0); ++bwd) {
             const bool cplx = (rt.flags & 1) != 0 || (bwd && !p->real_amp_grad);
             const int lgt = rt.variant == 0 ? ((bwd && cplx) ? 9 : 10) : rt.chain_lgt;

@@ -92,6 +92,69 @@ def test_conditioned_flips_and_ones_counting_terms_through_the_c_abi(cuda_device
         assert rel_err(got.grad.detach().cpu().numpy(), ref.grad.numpy()) < 1e-8, name
 
 
+@pytest.mark.parametrize("n_qubits,batch,variant,tape", [(14, 2, 2, "full"), (14, 1, 4, "steps"), (16, 1, 3, "full"), (20, 1, 0, "full"),
+                                                         (22, 1, 4, "steps"), (24, 1, 2, "partial")])
+def test_conditioned_flips_on_the_chained_tiles_match_the_direct_kernels(cuda_device, n_qubits, batch, variant, tape):
+    """Three-level style problems (every flip conditioned on its sibling qubit, ones-counting detunings) on the chained LDS-tile passes —
+    512 / 1024 / 256 threads forced at 14 / 16 / 22 / 24 qubits, the automatic choice at 20 (two tile layouts up to 22, three at 24;
+    tiles of 2^12 amplitudes, which keep sibling pairs together; beyond 20 qubits automatic stays on the direct kernels, which are faster there) — against the generic one-amplitude-per-thread kernels: <O>(t_k), the
+    final state (on the device), every gradient kind, all three tape modes; the unused code 00 stays empty."""
+    from pulser_diff_amd.solver import ProblemSpec, SolverType, evolve
+
+    gen = torch.Generator().manual_seed(177 + n_qubits)
+    ns, dt = 7, 0.004
+    n_atoms = n_qubits // 2
+    a_mask, b_mask = sum(1 << (2 * i) for i in range(n_atoms)), sum(1 << (2 * i + 1) for i in range(n_atoms))
+    amp_masks, amp_cond = (a_mask, 1 << 1, b_mask & ~(1 << 1)), (True, True, True)
+    det_masks, det_ones = (a_mask, b_mask, 1 << 0), (False, True, False)
+    amp = (torch.randn(1, 3, ns, generator=gen, dtype=torch.complex128) * 3.0).to(cuda_device)
+    det = (torch.randn(1, 3, ns, generator=gen, dtype=torch.float64) * 2.0).to(cuda_device)
+    pairs = list(itertools.combinations(range(n_qubits), 2))
+    u = torch.tensor([float(5.0 + 7.0 * torch.rand(1, generator=gen)) if (i % 2 == 0 and j % 2 == 0) else 0.0 for i, j in pairs],
+                     dtype=torch.float64).to(cuda_device)
+    tsave = torch.tensor([0.0, 0.004, 0.0095, 0.013, 0.0211], dtype=torch.float64)
+    # a few valid basis states (codes 01, 11, 10 per atom: never 00)
+    psi = torch.zeros(batch, 2**n_qubits, dtype=torch.complex128, device=cuda_device)
+    for b in range(batch):
+        for _ in range(5):
+            codes = torch.randint(1, 4, (n_atoms,), generator=gen)
+            x = int(sum(int(c) << (2 * k) for k, c in enumerate(codes)))
+            psi[b, x] += complex(torch.randn(1, generator=gen).item(), torch.randn(1, generator=gen).item())
+    psi = psi / psi.norm(dim=1, keepdim=True)
+    x = torch.arange(2**n_qubits, device=cuda_device)
+    obs = ((x * 2654435761) % 1000003).to(torch.float64)[None] / 1000003.0
+    invalid = torch.zeros(2**n_qubits, dtype=torch.bool, device=cuda_device)
+    for k in range(n_atoms):
+        invalid |= ((x >> (2 * k)) & 3) == 0
+    del x
+    out = {}
+    for v in (1, variant):
+        spec = ProblemSpec(n_qubits, dt, ns, amp_masks, det_masks, solver=SolverType.KRYLOV_SE, store_states=False,
+                           amp_conditioned=amp_cond, det_ones=det_ones, kernel_variant=v, tape=tape,
+                           tape_steps=2 if tape == "partial" else None)
+        leaves = [amp.clone().requires_grad_(True), det.clone().requires_grad_(True), u.clone().requires_grad_(True),
+                  tsave.clone().requires_grad_(True), psi.clone().requires_grad_(True)]
+        _, expect = evolve(*leaves, spec, obs)
+        w = torch.linspace(0.4, 1.3, len(tsave), dtype=torch.float64, device=cuda_device)
+        (expect[0] * w[:, None]).sum().backward()
+        st = dict(spec.options["_last_stats"])
+        assert st["kernel_family"] == ("direct" if v == 1 else "chained-tiles"), st
+        assert st["tape"] == tape
+        out[v] = [expect.detach()] + [t.grad.detach().to(cuda_device) for t in leaves]
+        del leaves, expect, _
+        torch.cuda.empty_cache()
+    for name, ref, got in zip(("expect", "amp", "det", "u", "tsave", "psi0"), out[1], out[variant]):
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= 1e-9 * max(scale, 1e-30), name
+    spec = ProblemSpec(n_qubits, dt, ns, amp_masks, det_masks, solver=SolverType.KRYLOV_SE, store_states=True,
+                       amp_conditioned=amp_cond, det_ones=det_ones, kernel_variant=variant)
+    with torch.no_grad():
+        states, _ = evolve(amp, det, u, tsave, psi, spec, obs)
+    assert dict(spec.options["_last_stats"])["kernel_family"] == "chained-tiles"
+    assert (states.abs().square().sum(-1) - 1).abs().max() < 1e-11
+    assert float(states[..., invalid].abs().max()) == 0.0  # the unused code 00 of every atom stays empty
+
+
 @pytest.mark.parametrize("solver_name", ["KRYLOV_SE", "DP5_SE"])
 @pytest.mark.parametrize("local_raman", [True, False])
 def test_three_level_sequence_through_the_emulator(cuda_device, solver_name, local_raman):
