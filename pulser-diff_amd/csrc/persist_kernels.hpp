@@ -87,14 +87,33 @@ __device__ __forceinline__ void stage_factors(const PersistFactor* __restrict__ 
 // FAST (implies SMALLG): one amplitude group driving every qubit (a global channel) and at most one detuning group — no
 // group loops, no mask tests.
 // GLMAX: group slots the SMALLG instantiation loops over (2 when there are at most two amplitude and two detuning groups).
-template <int LT, int LGT, bool CPLX, bool SMALLG, bool FAST = false, int GLMAX = kPersistGroups>
+// PERBIT (forward sweep; !SMALLG): every amplitude group and every detuning group is ONE qubit — the term structure of the stochastic-noise
+// runs (backend._run_noisy: one single-qubit amplitude and detuning term per atom, per-trajectory tables) and of sequences with several
+// local channels.  The generic path loops over the groups (a partner-sum call with zeroed accumulators per group, a popcount per detuning
+// group and amplitude, 3 N coefficients read from global memory per factor): 4-7 x the time of the global-drive sweep.  Here the
+// coefficient record is staged in LDS like SMALLG's, the detuning diagonal is a per-thread sum over the lane bits plus the register bits,
+// and every partner read is multiplied by its own qubit's coefficient (beta c where the own bit is set, beta conj(c) where not).
+template <int LT, int LGT, bool CPLX, bool SMALLG, bool FAST = false, int GLMAX = kPersistGroups, bool PERBIT = false>
 __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist(PersistArgs a) {
+    static_assert(!PERBIT || (!SMALLG && !FAST), "PERBIT replaces the generic group loops");
     constexpr int GL = FAST ? 1 : GLMAX;
     constexpr int NT = 1 << LGT, R = 1 << (LT - LGT), NTL = NT < 64 ? 64 : NT, NW = NTL / 64;
     __shared__ __attribute__((aligned(16))) double2 tile[1 << LT];
     __shared__ double red[NW];
     __shared__ PersistFactor sfac[kStageChunk];
     __shared__ double scoef[SMALLG ? kStageChunk : 1][kStageNC];
+    __shared__ double scoef_pb[PERBIT ? kStageChunk : 1][3 * LT];  // PERBIT: c_re[ga], c_im[ga], dcoef[gd] of the staged factors
+    int ga_of[LT], gd_of[LT];  // PERBIT: group (coefficient slot) of tile bit b = amplitude-index bit b, -1: not driven (uniform)
+    if constexpr (PERBIT) {
+#pragma unroll
+        for (int bb = 0; bb < LT; ++bb) {
+            ga_of[bb] = gd_of[bb] = -1;
+            for (int g = 0; g < a.ga; ++g)
+                if (a.amask[g] == (1u << bb)) ga_of[bb] = g;
+            for (int g = 0; g < a.gd; ++g)
+                if (a.dmask[g] == (1u << bb)) gd_of[bb] = g;
+        }
+    }
     __shared__ double2 spair[RYDIFF_MAX_PAIR_TERMS * 32];
     for (int i = int(threadIdx.x); i < a.pair.n * 32; i += NTL) spair[i] = a.pair.tab[i];  // published by the first barrier
     const unsigned tid0 = threadIdx.x;
@@ -128,6 +147,12 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist(P
         if (fs == 0) {
             const int count = a.n_factors - f < kStageChunk ? a.n_factors - f : kStageChunk;
             stage_factors<NTL>(a.factors, f, count, coef_b, a.NC, SMALLG, sfac, scoef);
+            if constexpr (PERBIT) {
+                for (int t = int(threadIdx.x); t < count * a.NC; t += NTL) {
+                    const int ft = t / a.NC, c = t - ft * a.NC;
+                    scoef_pb[ft][c] = coef_b[size_t(a.factors[f + ft].stage) * a.NC + c];
+                }
+            }
             __syncthreads();
         }
         unsigned tid = tid0;
@@ -137,7 +162,49 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist(P
         const double* cfs = scoef[SMALLG ? fs : 0];                          // SMALLG (LDS)
         auto cf = [&](int c) -> double { return SMALLG ? cfs[c] : cfg[c]; };
         double2 q[R];
-        if (active) {
+        if constexpr (PERBIT) {
+            if (active) {
+                const double* cpb = scoef_pb[fs];
+                double dlane = 0.0;  // detuning of the lane bits that are in |r> (bit = 0)
+#pragma unroll
+                for (int bb = 0; bb < LGT; ++bb)
+                    if (gd_of[bb] >= 0 && !(tid >> bb & 1u)) dlane += cpb[2 * a.ga + gd_of[bb]];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    double d = ud[r] + dlane;
+#pragma unroll
+                    for (int bb = LGT; bb < LT; ++bb)
+                        if (gd_of[bb] >= 0 && !(r >> (bb - LGT) & 1)) d += cpb[2 * a.ga + gd_of[bb]];
+                    const double dr = pf.gr + pf.br * d, di = pf.gi + pf.bi * d;
+                    q[r].x = dr * v[r].x - di * v[r].y;
+                    q[r].y = dr * v[r].y + di * v[r].x;
+                }
+                auto flip_bit = [&](auto bc) {
+                    constexpr int bb = decltype(bc)::value;
+                    if (ga_of[bb] < 0) return;  // uniform
+                    const double cr = cpb[ga_of[bb]], ci = cpb[a.ga + ga_of[bb]];
+                    const double k1r = pf.br * cr - pf.bi * ci, k1i = pf.br * ci + pf.bi * cr;  // beta c       (own bit set)
+                    const double k0r = pf.br * cr + pf.bi * ci, k0i = pf.bi * cr - pf.br * ci;  // beta conj(c) (own bit clear)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        double2 pv;
+                        bool own;
+                        if constexpr (bb >= LGT) {
+                            pv = v[r ^ (1 << (bb >= LGT ? bb - LGT : 0))];
+                            own = (r >> (bb >= LGT ? bb - LGT : 0)) & 1;
+                        } else {
+                            if constexpr (LT <= 6) pv = lanes ? lane_xor<(bb < 6 ? bb : 0)>(v[r]) : tile[(unsigned(r) * NT + tid) ^ (1u << bb)];
+                            else pv = tile[(unsigned(r) * NT + tid) ^ (1u << bb)];
+                            own = (tid >> bb) & 1u;
+                        }
+                        const double kr = own ? k1r : k0r, ki = own ? k1i : k0i;
+                        q[r].x += kr * pv.x - ki * pv.y;
+                        q[r].y += kr * pv.y + ki * pv.x;
+                    }
+                };
+                static_for<0, LT>(flip_bit);
+            }
+        } else if (active) {
             double dsh[R];  // time-dependent part of the diagonal
 #pragma unroll
             for (int r = 0; r < R; ++r) dsh[r] = ud[r];

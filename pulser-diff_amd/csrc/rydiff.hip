@@ -1895,11 +1895,31 @@ int run_chain_bwd(const Runtime& rt, char* ws, const std::vector<ChainItem>& ite
 // ---- persistent small-N forward (k_persist) ------------------------------------------------------------------------
 bool persist_enabled(const Runtime& rt) { return rt.variant != 1 && rt.pl.N <= kTileBits && !rt.pl.shard_bits; }
 
+// every amplitude and every detuning group is ONE qubit and there are more than two of either (stochastic-noise runs, several local
+// channels): the per-bit form of the forward sweep (k_persist<..., PERBIT>) instead of the generic group loops
+bool per_bit_terms(const PersistArgs& pa) {
+    auto single = [](uint32_t m) { return m != 0 && (m & (m - 1)) == 0; };
+    if (pa.pair.n || pa.cond || (pa.ga <= 2 && pa.gd <= 2)) return false;
+    uint32_t seen = 0;
+    for (int g = 0; g < pa.ga; ++g) {
+        if (!single(pa.amask[g]) || (seen & pa.amask[g])) return false;
+        seen |= pa.amask[g];
+    }
+    seen = 0;
+    for (int g = 0; g < pa.gd; ++g) {
+        if (!single(pa.dmask[g]) || (seen & pa.dmask[g]) || pa.dcnt[g] != 1) return false;
+        seen |= pa.dmask[g];
+    }
+    return true;
+}
+
 template <int LT, bool CPLX>
 int launch_persist_t(const PersistArgs& pa, int B, hipStream_t stream) {
     constexpr int LGT = LT < 10 ? LT : 10;
     const dim3 block(LGT < 6 ? 64 : (1 << LGT));
-    if (pa.ga == 1 && pa.gd <= 1 && pa.amask[0] == (1u << LT) - 1u && pa.pair.n == 0 && pa.cond == 0)
+    if (per_bit_terms(pa) && pa.NC <= 3 * LT)
+        hipLaunchKernelGGL((k_persist<LT, LGT, true, false, false, kPersistGroups, true>), dim3(B), block, 0, stream, pa);
+    else if (pa.ga == 1 && pa.gd <= 1 && pa.amask[0] == (1u << LT) - 1u && pa.pair.n == 0 && pa.cond == 0)
         hipLaunchKernelGGL((k_persist<LT, LGT, CPLX, true, true>), dim3(B), block, 0, stream, pa);
     else if (pa.ga <= 2 && pa.gd <= 2)
         hipLaunchKernelGGL((k_persist<LT, LGT, CPLX, true, false, 2>), dim3(B), block, 0, stream, pa);
@@ -1930,7 +1950,7 @@ bool lanes_enabled(int variant, int N, int ga, int gd, int n_pair) {
 
 template <bool CPLX>
 int launch_persist(int variant, int N, const PersistArgs& pa, int B, hipStream_t stream) {
-    if (lanes_enabled(variant, N, pa.ga, pa.gd, pa.pair.n) && pa.n_factors > 0) {
+    if (lanes_enabled(variant, N, pa.ga, pa.gd, pa.pair.n) && pa.n_factors > 0) {  // (up to 4 groups: also ahead of the per-bit sweep, 0.83 vs 0.90 us per factor at 4 qubits)
         switch (N) {
             case 1: return launch_lanes_fwd_t<1, CPLX>(pa, B, stream);
             case 2: return launch_lanes_fwd_t<2, CPLX>(pa, B, stream);

@@ -279,6 +279,51 @@ def test_chained_tile_kernels_match_direct_kernels(cuda_device, n_qubits, local,
         assert rel_err(got[key].cpu().numpy(), ref[key].cpu().numpy()) < (1e-10 if n_qubits < 21 else 1e-9), key
 
 
+@pytest.mark.parametrize("n_qubits,batch,solver_name,grads", [(5, 4, "KRYLOV_SE", True), (6, 3, "DP5_SE", True), (7, 5, "KRYLOV_SE", False),
+                                                            (8, 3, "KRYLOV_SE", True), (10, 2, "DP5_SE", False), (11, 2, "KRYLOV_SE", True),
+                                                            (12, 2, "KRYLOV_SE", True)])
+def test_per_atom_terms_on_the_one_workgroup_sweep_match_direct_kernels(cuda_device, n_qubits, batch, solver_name, grads):
+    """ONE single-qubit amplitude term and ONE single-qubit detuning term per atom with per-trajectory tables — what the stochastic-noise
+    runs hand over (backend._run_noisy; from 7 qubits on all but one atom driven and all but another detuned) — on the per-bit form of the one-workgroup
+    forward sweep (k_persist<..., PERBIT>) against the direct kernels: every stored state, <O>(t_k) and, where asked, every gradient
+    kind (the adjoint sweeps are the existing ones: they read the tape / the states this forward sweep wrote)."""
+    from pulser_diff_amd import _native
+    from pulser_diff_amd.solver import ProblemSpec, SolverType, evolve
+
+    gen = torch.Generator().manual_seed(900 + n_qubits)
+    ns, dt = 9, 0.003
+    t = torch.linspace(0, 1, ns, dtype=torch.float64)
+    amp_q = [q for q in range(n_qubits) if q != 1 or n_qubits < 7]  # (5 / 6 qubits: every atom, so that there are more than 4 groups)
+    det_q = [q for q in range(n_qubits) if q != n_qubits - 1 or n_qubits < 7]
+    amp = (0.5 * 7.0 * torch.sin(torch.pi * t) ** 2)[None, None] * (1.0 + 0.2 * torch.randn(batch, len(amp_q), 1, generator=gen, dtype=torch.float64))
+    amp = (amp * torch.exp(-1j * (0.5 * t + 0.3 * torch.rand(batch, len(amp_q), 1, generator=gen, dtype=torch.float64)))).to(torch.complex128).to(cuda_device)
+    det = ((-0.5 * (-4.0 + 8.0 * t))[None, None] + 0.7 * torch.randn(batch, len(det_q), 1, generator=gen, dtype=torch.float64)).to(cuda_device).contiguous()
+    coords = torch.stack([torch.arange(n_qubits, dtype=torch.float64) * 7.5, torch.rand(n_qubits, generator=gen, dtype=torch.float64)], 1)
+    u = R.interaction_strengths(coords).to(cuda_device)
+    tsave = torch.tensor([0.0, 0.0041, 0.0093, 0.0150, 0.0222], dtype=torch.float64)
+    psi = torch.randn(batch, 2**n_qubits, generator=gen, dtype=torch.complex128)
+    psi = (psi / psi.norm(dim=1, keepdim=True)).to(cuda_device)
+    obs = torch.rand(2, 2**n_qubits, generator=gen, dtype=torch.float64).to(cuda_device)
+    masks_a, masks_d = tuple(1 << q for q in amp_q), tuple(1 << q for q in det_q)
+    out = {}
+    for variant in (1, 0):
+        spec = ProblemSpec(n_qubits, dt, ns, masks_a, masks_d, solver=SolverType[solver_name], store_states=True, kernel_variant=variant)
+        leaves = [amp.clone().requires_grad_(grads), det.clone().requires_grad_(grads), u.clone().requires_grad_(grads),
+                  tsave.clone().requires_grad_(grads), psi.clone().requires_grad_(grads)]
+        if grads:
+            states, expect = evolve(*leaves, spec, obs)
+            w = torch.linspace(0.3, 1.2, len(tsave), dtype=torch.float64, device=cuda_device)
+            ((expect[0] * w[:, None]).sum() - 0.4 * expect[1, 2].sum() + (states[-1, :, 1].real * 0.6).sum()).backward()
+        else:
+            with torch.no_grad():
+                states, expect = evolve(*leaves, spec, obs)
+        st = dict(spec.options["_last_stats"])
+        assert st["kernel_family"] == ("direct" if variant == 1 else "persistent"), st  # (more than 4 groups: not the one-wave lane kernels)
+        out[variant] = [states.detach(), expect.detach()] + ([l.grad.detach().to(cuda_device) for l in leaves] if grads else [])
+    for name, ref, got in zip(("states", "expect", "amp", "det", "u", "tsave", "psi0"), out[1], out[0]):
+        assert float((got - ref).abs().max()) <= 1e-10 * max(float(ref.abs().max()), 1e-30), name
+
+
 @pytest.mark.parametrize("n", [29, 30])
 def test_chained_passes_at_29_and_30_qubits_match_direct_kernels(cuda_device, n):
     """29 / 30 qubits (8 / 16 GiB per vector; 2^12 tiles end at 28, the direct kernels were used beyond): three layouts of WIDE tiles,
