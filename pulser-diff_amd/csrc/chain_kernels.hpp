@@ -285,8 +285,9 @@ __device__ unsigned long long g_timeline[4096 * 8];  // tuning builds: per-workg
 #define RYDIFF_TL(slot)
 #endif
 
-// FAST: exactly one amplitude group, every tile bit in its start-stage mask and no partner-tile loads (a global drive), at
-// most one detuning group: straight-line code instead of the runtime group loops, no mask tests in the start stage.
+// FAST: exactly one amplitude group, every tile bit in its start-stage mask and no partner-tile loads (a global drive): straight-line
+// code instead of the runtime group loops, no mask tests in the start stage.  The first detuning group is straight-line too; further
+// ones (local detuning channels next to the global drive) cost a uniform loop over the diagonal only.
 // RES: the vectors of a trajectory are meant to STAY in the XCD's L2 (trajectory-per-XCD placement): plain loads / stores instead
 // of the streaming (non-temporal) ones.  A template parameter on purpose: selecting the access flavour at run time made the
 // compiler merge both flavours into plain accesses and the 20-qubit pass lost its streaming hints (15.4 vs 13.9 us).
@@ -542,13 +543,23 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
                     const double cnt = GD ? double(a.dcnt[0] - popc_i((xg[r] | rank_hi) & a.dmask[0])) : 0.0;
                     sgd += w * cnt;
                     if (!exact_fin) {  // Re <mu' - (gamma~ + beta~ d) mu, x>
-                        const double d = du[r] + cdet * cnt;
+                        double d = du[r] + cdet * cnt;
+                        for (int g = 1; g < a.gd; ++g) d += cf[2 + g] * double(a.dcnt[g] - popc_i((xg[r] | rank_hi) & a.dmask[g]));
                         const double dr = a.fg_r + a.fb_r * d, di = a.fg_i + a.fb_i * d;
                         const double wx = acc[r].x - (dr * uu[r].x - di * uu[r].y), wy = acc[r].y - (dr * uu[r].y + di * uu[r].x);
                         zr += wx * xf[r].x + wy * xf[r].y;
                     }
                 }
                 if (GD) park1<NW>(sgd, red, 2 * a.ga);
+                for (int g = 1; g < a.gd; ++g) {  // further detuning groups next to the one global drive (local detuning channels)
+                    double sg = 0.0;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const double pr = a.cb_fin_r * uu[r].x + a.cb_fin_i * uu[r].y, pi = a.cb_fin_i * uu[r].x - a.cb_fin_r * uu[r].y;
+                        sg += (pr * xf[r].x - pi * xf[r].y) * double(a.dcnt[g] - popc_i((xg[r] | rank_hi) & a.dmask[g]));
+                    }
+                    park1<NW>(sg, red, 2 * a.ga + g);
+                }
                 if (!exact_fin) park1<NW>(zr / cf[0], red, 0);
             }
         }
@@ -621,7 +632,7 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
             rr[r] = pr * xs[r].x - pi * xs[r].y;
             if (a.wtot) unsafeAtomicAdd(a.wtot + (a.sh_bits ? boff : 0) + xg[r], rr[r]);
         }
-        for (int g = 0; g < GD; ++g) {
+        for (int g = 0; g < a.gd; ++g) {
             double sgd = 0.0;
 #pragma unroll
             for (int r = 0; r < R; ++r) sgd += rr[r] * double(a.dcnt[g] - popc_i((xg[r] | rank_hi) & a.dmask[g]));
@@ -632,8 +643,9 @@ __global__ __launch_bounds__(1 << LGT) void k_chain(ChainArgs a) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         double d = du[r];
-        if (FAST) {
+        if (FAST) {  // one global drive: the first detuning group straight-line, further ones (local detuning channels) in a uniform loop
             if (GD) d += cf[2] * double(a.dcnt[0] - popc_i((xg[r] | rank_hi) & a.dmask[0]));
+            for (int g = 1; g < a.gd; ++g) d += cf[2 + g] * double(a.dcnt[g] - popc_i((xg[r] | rank_hi) & a.dmask[g]));
         } else {
             for (int g = 0; g < a.gd; ++g) d += cf[2 * a.ga + g] * double(a.dcnt[g] - popc_i((xg[r] | rank_hi) & a.dmask[g]));
         }
@@ -910,13 +922,25 @@ __global__ __launch_bounds__(1024) void k_chain_wide(ChainArgs a) {
                         const double cnt = GD ? double(a.dcnt[0] - popc_i((x | rank_hi) & a.dmask[0])) : 0.0;
                         sgd += w * cnt;
                         if (!exact_fin) {  // Re <mu' - (gamma~ + beta~ d) mu, x>
-                            const double d = diag_of(rf, dlane) + cdet * cnt;
+                            double d = diag_of(rf, dlane) + cdet * cnt;
+                            for (int g = 1; g < a.gd; ++g) d += cf[2 + g] * double(a.dcnt[g] - popc_i((x | rank_hi) & a.dmask[g]));
                             const double dr = a.fg_r + a.fb_r * d, di = a.fg_i + a.fb_i * d;
                             const double wx = acc[rf].x - (dr * mu.x - di * mu.y), wy = acc[rf].y - (dr * mu.y + di * mu.x);
                             zr += wx * xf[r].x + wy * xf[r].y;
                         }
                     }
                     if (GD) park1<NW>(sgd, red, 2 * a.ga);
+                    for (int g = 1; g < a.gd; ++g) {  // further detuning groups next to the one global drive
+                        double sg = 0.0;
+#pragma unroll
+                        for (int r = 0; r < RH; ++r) {
+                            const int rf = h * RH + r;
+                            const double2 mu = tile[unsigned(rf) * NT + tid];
+                            const double pr = a.cb_fin_r * mu.x + a.cb_fin_i * mu.y, pi = a.cb_fin_i * mu.x - a.cb_fin_r * mu.y;
+                            sg += (pr * xf[r].x - pi * xf[r].y) * double(a.dcnt[g] - popc_i((xg_of(rf) | rank_hi) & a.dmask[g]));
+                        }
+                        park1<NW>(sg, red, 2 * a.ga + g);
+                    }
                     if (!exact_fin) park1<NW>(zr / cf[0], red, 0);
                 }
             }
@@ -984,6 +1008,7 @@ __global__ __launch_bounds__(1024) void k_chain_wide(ChainArgs a) {
             const unsigned x = xg_of(rf) | rank_hi;
             if (FAST) {
                 if (GD) d += cf[2] * double(a.dcnt[0] - popc_i(x & a.dmask[0]));
+                for (int g = 1; g < a.gd; ++g) d += cf[2 + g] * double(a.dcnt[g] - popc_i(x & a.dmask[g]));
             } else {
                 for (int g = 0; g < a.gd; ++g) d += cf[2 * a.ga + g] * double(a.dcnt[g] - popc_i(x & a.dmask[g]));
             }
@@ -1000,7 +1025,7 @@ __global__ __launch_bounds__(1024) void k_chain_wide(ChainArgs a) {
                 rr[r] = pr * xs[r].x - pi * xs[r].y;
                 if (a.wtot) unsafeAtomicAdd(a.wtot + (a.sh_bits ? boff : 0) + xg_of(rf), rr[r]);
             }
-            for (int g = 0; g < GD; ++g) {
+            for (int g = 0; g < a.gd; ++g) {
                 double sgd = 0.0;
 #pragma unroll
                 for (int r = 0; r < RH; ++r) sgd += rr[r] * double(a.dcnt[g] - popc_i((xg_of(h * RH + r) | rank_hi) & a.dmask[g]));

@@ -1591,7 +1591,7 @@ template <int LT, int LGT, bool CPLX, bool BWD, bool FAST = false, bool RES = fa
 int launch_chain_t(const ChainArgs& ca, unsigned tiles, hipStream_t stream) {
     static_assert(LT == kTileBits || (LT >= kSmallTileBits && LT <= kWideTileBits && LGT == 10 && !RES), "other tile sizes: 1024 threads, no L2-resident placement");
     if constexpr (!FAST) {  // one global drive, at most one detuning group: the loop-free instantiation
-        if (ca.ga == 1 && ca.gd <= 1 && ca.sta_mask[0] == (1u << LT) - 1u && !ca.cond)
+        if (ca.ga == 1 && ca.sta_mask[0] == (1u << LT) - 1u && !ca.cond)  // (any number of detuning groups)
             return launch_chain_t<LT, LGT, CPLX, BWD, true, RES>(ca, tiles, stream);
     }
     // tile + reduction scratch: one double per wave (forward), [4 ga + gd] slots per wave (adjoint: parked gradient partials)
@@ -2116,7 +2116,7 @@ void describe_kernels(const Runtime& rt, const RydProblem* p, bool backward, Ryd
     auto b = [](bool v) { return v ? "true" : "false"; };
     info->kernel_fwd[0] = info->kernel_bwd[0] = 0;
     if (info->kernel_family == 3) {
-        const bool fast = pl.ga.n == 1 && pl.gd.n <= 1 && (pl.ga.amp_index_mask[0] & ((1u << pl.NL) - 1u)) == (1u << pl.NL) - 1u && !pl.ga.flagged;
+        const bool fast = pl.ga.n == 1 && (pl.ga.amp_index_mask[0] & ((1u << pl.NL) - 1u)) == (1u << pl.NL) - 1u && !pl.ga.flagged;
         for (int bwd = 0; bwd <= (backward ? 1 : 0); ++bwd) {
             const bool cplx = (rt.flags & 1) != 0 || (bwd && !p->real_amp_grad);
             const int lgt = rt.variant == 0 ? ((bwd && cplx) ? 9 : 10) : rt.chain_lgt;

@@ -279,6 +279,56 @@ def test_chained_tile_kernels_match_direct_kernels(cuda_device, n_qubits, local,
         assert rel_err(got[key].cpu().numpy(), ref[key].cpu().numpy()) < (1e-10 if n_qubits < 21 else 1e-9), key
 
 
+@pytest.mark.parametrize("n_qubits,variant,real_tables,tape", [(14, 2, True, "full"), (14, 4, False, "steps"), (15, 14, True, "full"), (16, 15, True, "steps"),
+                                                             (20, 0, True, "full"), (22, 0, True, "steps"), (22, 0, False, "full")])
+def test_global_drive_with_local_detuning_channels_on_the_loop_free_chained_kernels(cuda_device, n_qubits, variant, real_tables, tape):
+    """ONE global drive and several detuning groups (a global detuning plus local detuning channels on two subsets of the atoms): the
+    loop-free chained instantiations (FAST; with a phase-free real drive the single-tape-read adjoint) take every detuning group — the
+    first straight-line, the others in a uniform loop over the diagonal — on 2^12, 2^11 and wide tiles, against the generic direct
+    kernels: <O>(t_k), every gradient kind, both tape modes."""
+    from pulser_diff_amd import _native
+    from pulser_diff_amd.solver import ProblemSpec, SolverType, evolve
+
+    terms = random_terms(n_qubits, 11, 0.003, seed=640 + n_qubits, local=False, phase=not real_tables)
+    t = torch.linspace(0, 1, 11, dtype=torch.float64)
+    terms.extra_det = [(-0.5 * 3.0 * torch.sin(2.5 * t), [1, 4, n_qubits - 1]), (-0.5 * 1.7 * torch.cos(1.3 * t), [4, 6])]
+    tsave = torch.tensor([0.0, 0.0052, 0.0111, 0.0187, 0.0270], dtype=torch.float64)
+    psi = torch.zeros(1, 2**n_qubits, dtype=torch.complex128, device=cuda_device)
+    psi[0, -1], psi[0, 777], psi[0, 2**n_qubits // 3] = 0.7, 0.5j, -0.5099019513592785
+    x = torch.arange(2**n_qubits, device=cuda_device)
+    obs = torch.zeros(2**n_qubits, dtype=torch.float64, device=cuda_device)
+    for j in range(n_qubits):
+        obs += (1.0 + 0.1 * j) * (1.0 - 2.0 * ((x >> j) & 1).to(torch.float64))
+    del x
+    out = {}
+    for v in (9, variant):
+        _native.set_kernel_variant(v)
+        try:
+            amp, det, u, spec = to_native(terms, cuda_device, SolverType.KRYLOV_SE, store_states=False)
+            spec.tape = tape
+            if real_tables:
+                assert float(amp.imag.abs().max()) == 0.0
+                amp = amp.real.contiguous()
+            ts = tsave.clone().requires_grad_(True)
+            for t_ in (amp, det, u):
+                t_.requires_grad_(True)
+            _, expect = evolve(amp, det, u, ts, psi, spec, obs[None])
+            (expect[0, :, 0] * torch.tensor([0.2, -0.4, 0.9, 0.3, 1.1], dtype=torch.float64, device=cuda_device)).sum().backward()
+            st = dict(spec.options["_last_stats"])
+            out[v] = [expect.detach().cpu(), amp.grad.cpu(), det.grad.cpu(), u.grad.cpu(), ts.grad.cpu()]
+            if v != 9:
+                assert st["kernel_family"] == "chained-tiles" and st["kernel_fwd"].endswith(",true,false>" if "wide" not in st["kernel_fwd"] else ",true>"), st
+                assert det.shape[1] >= 3  # the global detuning and the two local channels
+            del expect, _
+            torch.cuda.empty_cache()
+        finally:
+            _native.set_kernel_variant(0)
+    # (the single-tape-read adjoint recovers the drive gradient from a difference: up to 14 of 53 bits, see chain_kernels.hpp REC;
+    # the detuning gradients here are 1e-6 of the amplitude gradients' size)
+    for name, ref, got in zip(("expect", "amp", "det", "u", "tsave"), out[9], out[variant]):
+        assert rel_err(got.numpy(), ref.numpy()) < 1e-9, name
+
+
 @pytest.mark.parametrize("n_qubits,batch,solver_name,grads", [(5, 4, "KRYLOV_SE", True), (6, 3, "DP5_SE", True), (7, 5, "KRYLOV_SE", False),
                                                             (8, 3, "KRYLOV_SE", True), (10, 2, "DP5_SE", False), (11, 2, "KRYLOV_SE", True),
                                                             (12, 2, "KRYLOV_SE", True)])

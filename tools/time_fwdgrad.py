@@ -25,14 +25,15 @@ coords = torch.tensor([[8.0 * i, 8.0 * j] for i in range(rows) for j in range(n 
 iu = torch.triu_indices(n, n, 1)
 u = (5420158.53 / (coords[iu[0]] - coords[iu[1]]).norm(dim=1) ** 6).to(dev)
 amp = torch.full((B, 1, T + 1), 3.5, dtype=torch.float64 if real else torch.complex128, device=dev, requires_grad=True)
-det = torch.full((B, 1, T + 1), -1.0, dtype=torch.float64, device=dev, requires_grad=True)
+n_loc = int(os.environ.get("LOCAL_DET", "0"))  # LOCAL_DET=k: k local detuning channels (one atom each) next to the global drive
+det = torch.full((B, 1 + n_loc, T + 1), -1.0, dtype=torch.float64, device=dev, requires_grad=True)
 psi0 = torch.zeros(B, 2**n, dtype=torch.complex128, device=dev)
 psi0[:, -1] = 1
 ts = torch.arange(T + 1, dtype=torch.float64) / 1000
 x = torch.arange(2**n, device=dev)
 zdiag = sum(1.0 - 2.0 * ((x >> j) & 1).to(torch.float64) for j in range(n))
 mask = (1 << n) - 1
-spec = ProblemSpec(n, 0.001, T + 1, (mask,), (mask,), solver=SolverType.KRYLOV_SE, store_states=False,
+spec = ProblemSpec(n, 0.001, T + 1, (mask,), (mask,) + tuple(1 << (3 * k + 1) for k in range(n_loc)), solver=SolverType.KRYLOV_SE, store_states=False,
                    tape=os.environ.get("TAPE", "auto"), tape_steps=int(os.environ["TAPE_STEPS"]) if "TAPE_STEPS" in os.environ else None)  # TAPE=steps|full|partial|auto
 for it in range(3):
     torch.cuda.synchronize()
