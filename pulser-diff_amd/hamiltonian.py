@@ -207,7 +207,77 @@ class Hamiltonian:
         """Coefficient tables of ``n_runs`` noise realisations as ONE batch: (amp_tables [R, K_a, n], det_tables
         [R, K_d, n], amp_masks, det_masks), one single-qubit term per addressed atom.  ``bad_atoms`` (list of per-atom
         bool tuples) fixes the state-preparation errors of each run instead of redrawing all noise
-        (``backend.py:575-587``: ``update=False``)."""
+        (``backend.py:575-587``: ``update=False``).
+
+        The realisations are DRAWN run by run, in the order ``_update_noise`` / ``_extract_samples`` draw them (the random stream of
+        a seeded call is that of the per-run loop), but applied to the per-atom samples for all runs at once: the per-run Python loop
+        over atoms, pulses and sample windows (``noisy_batch_tables_per_run``, kept as the statement of the semantics and checked
+        against this one in tests/test_noise_host.py) was three quarters of a 100-run emulator call once the sampling moved to the
+        device."""
+        if not self._local_noises():
+            return self.noisy_batch_tables_per_run(n_runs, bad_atoms)
+        cfg = self._config
+        n, ns = self._size, int(self._sampling_rate * self._duration)
+        base = self.samples_obj.to_nested_dict(all_local=True, samples_type="tensor")  # the same for every run
+        if base["Global"]:
+            raise RuntimeError("noise realisations need per-qubit samples")
+        for basis, per_q in base["Local"].items():
+            if per_q and (basis != self.basis_name or self.basis_name == "all"):
+                raise NotImplementedError(f"Stochastic noise on {basis!r} samples in the {self.basis_name!r} basis is not supported.")
+        qids = list(self._qid_index)
+        channels = list(self.samples_obj.channel_samples.items())
+        bad = torch.zeros(n_runs, n, dtype=torch.bool)
+        doppler = torch.zeros(n_runs, n, dtype=RD)
+        factors = [torch.ones(n_runs, max(len(cs.slots), 1), dtype=torch.float32) for _, cs in channels]
+        keep = (self._bad_atoms, self._doppler_detune)
+        for r in range(n_runs):  # the draws, in the loop version's order
+            if bad_atoms is not None:
+                self._bad_atoms = dict(zip(self._qid_index, (bool(b) for b in bad_atoms[r])))
+            else:
+                self._update_noise()
+            bad[r] = torch.tensor([bool(self._bad_atoms[q]) for q in qids])
+            doppler[r] = torch.tensor([float(self._doppler_detune[q]) for q in qids], dtype=RD)
+            for c, (_, cs) in enumerate(channels):
+                factors[c][r] = torch.normal(torch.ones(max(len(cs.slots), 1)), float(cfg.amp_sigma)).clamp_min(0.0)
+        self._bad_atoms, self._doppler_detune = keep
+        shift_det = "doppler" in cfg.noise_types
+        scale_amp = "amplitude" in cfg.noise_types
+        beam = self._beam_profile() if scale_amp else None
+        amp = torch.zeros(n_runs, n, ns, dtype=CD)
+        det = torch.zeros(n_runs, n, ns, dtype=RD)
+        per_q = base["Local"].get(self.basis_name, {})
+        for qid, sq in per_q.items():
+            j = self._qid_index[qid]
+            amp_r = sq["amp"].detach().clone()[None].repeat(n_runs, 1)
+            det_r = sq["det"].detach().clone()[None].repeat(n_runs, 1)
+            for c, (ch, cs) in enumerate(channels):
+                info = self.samples_obj._ch_objs[ch]
+                if info.basis != self.basis_name:
+                    continue
+                for si, slot in enumerate(cs.slots):
+                    if qid not in slot.targets:
+                        continue
+                    window = slice(slot.ti, slot.tf)
+                    if shift_det:
+                        det_r[:, window] += doppler[:, j:j + 1]
+                    if scale_amp and info.addressing == "Global":
+                        amp_r[:, window] *= (factors[c][:, si].to(RD) * beam[qid])[:, None]
+            phase = sq["phase"].detach().to(CD)
+            rows = 0.5 * amp_r * torch.exp(-1j * phase)[None]
+            rows[bad[:, j]] = 0
+            det_r[bad[:, j]] = 0
+            idx = torch.linspace(0, rows.shape[1] - 1, ns, dtype=torch.int).long()
+            amp[:, j] = rows[:, idx]
+            det[:, j] = -0.5 * det_r[:, idx]
+        ka = [j for j in range(n) if bool(torch.any(amp[:, j] != 0))]
+        kd = [j for j in range(n) if bool(torch.any(det[:, j] != 0))]
+        dev = self._compute_device
+        return (amp[:, ka].contiguous().to(dev), det[:, kd].contiguous().to(dev), tuple(1 << j for j in ka),
+                tuple(1 << j for j in kd))
+
+    def noisy_batch_tables_per_run(self, n_runs: int, bad_atoms: Union[list, None] = None):
+        """The same tables built run by run through ``_update_noise`` / ``_extract_samples`` (hamiltonian.py:170-219, 270-286 restated
+        literally): the statement of the semantics, and the path of noise models without per-atom noise."""
         n, ns = self._size, int(self._sampling_rate * self._duration)
         amp = torch.zeros(n_runs, n, ns, dtype=CD)
         det = torch.zeros(n_runs, n, ns, dtype=RD)

@@ -55,6 +55,34 @@ def test_noise_realisations_become_per_run_single_qubit_tables():
     assert abs(shift1.item() - shift2.item()) < 1e-12 and det[k, 1, 300].item() == 0.0
 
 
+@pytest.mark.parametrize("noise,kwargs", [(("doppler", "amplitude", "SPAM"), dict(temperature=50.0, laser_waist=20.0, amp_sigma=0.05, eta=0.3)),
+                                          (("doppler",), dict(temperature=80.0)), (("amplitude",), dict(amp_sigma=0.1)),
+                                          (("SPAM", "amplitude"), dict(eta=0.5, amp_sigma=0.02, laser_waist=15.0)), (("SPAM",), dict(eta=0.4))])
+def test_batched_noise_tables_are_the_per_run_tables(noise, kwargs):
+    """noisy_batch_tables applies the realisations to all runs at once; the per-run loop through _update_noise / _extract_samples is the
+    statement of the semantics (hamiltonian.py:170-219, 270-286).  Same seed: the same draws in the same order, the same tables bit for bit
+    — two pulses on a global channel plus a local channel on one atom, with and without fixed preparation errors."""
+    reg = pl.Register.rectangle(1, 4, spacing=8, prefix="q")
+    seq = pl.Sequence(reg, pl.MockDevice)
+    seq.declare_channel("g", "rydberg_global")
+    seq.declare_channel("l", "rydberg_local", initial_target="q2")
+    seq.add(pl.Pulse.ConstantPulse(120, 5.0, 1.0, 0.3), "g")
+    seq.add(pl.Pulse(pl.BlackmanWaveform(100, 2.0), pl.RampWaveform(100, -2.0, 3.0), 0.6), "l")
+    seq.add(pl.Pulse.ConstantPulse(80, 2.0, -1.0, 0.0), "g")
+    cfg = P.SimConfig(noise=noise, runs=7, samples_per_run=2, **kwargs)
+    ham = P.TorchEmulator.from_sequence(seq, config=cfg, compute_device="cpu", sampling_rate=0.5)._hamiltonian
+    for bad in (None, [(True, False, False, True)] * 3 + [(False,) * 4] * 4):
+        torch.manual_seed(17)
+        fast = ham.noisy_batch_tables(7, bad)
+        after_fast = torch.rand(1)
+        torch.manual_seed(17)
+        slow = ham.noisy_batch_tables_per_run(7, bad)
+        after_slow = torch.rand(1)
+        assert fast[2] == slow[2] and fast[3] == slow[3]
+        assert torch.equal(fast[0], slow[0]) and torch.equal(fast[1], slow[1])
+        assert torch.equal(after_fast, after_slow)  # the same number of draws was consumed
+
+
 def test_doppler_detunings_follow_the_thermal_width():
     cfg = P.SimConfig(noise="doppler", temperature=100.0, runs=400)
     ham = _emulator(cfg, n=2)._hamiltonian
