@@ -1,0 +1,25 @@
+import cProfile, gc, pstats, sys, time
+sys.path.insert(0, "/root/repo")
+import torch
+import pulser_diff_amd as P
+from pulser_diff_amd import pulses as pl
+from pulser_diff_amd.solver import SolverType
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+reg = pl.Register.rectangle(1, n, spacing=8, prefix="q")
+seq = pl.Sequence(reg, pl.MockDevice)
+seq.declare_channel("g", "rydberg_global")
+seq.add(pl.Pulse(pl.BlackmanWaveform(500, 4.0), pl.RampWaveform(500, -3.0, 2.0), 0.0), "g")
+cfg = P.SimConfig(noise=("dephasing", "relaxation"), dephasing_rate=0.2, relaxation_rate=0.1)
+gc.collect(); gc.freeze()
+for it in range(3):
+    if it == 2:
+        pr = cProfile.Profile(); pr.enable()
+    t0 = time.perf_counter()
+    sim = P.TorchEmulator.from_sequence(seq, config=cfg, evaluation_times=0.2)
+    t1 = time.perf_counter()
+    res = sim.run(solver=SolverType.DP5_ME)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    if it == 2: pr.disable()
+print(f"{n} atoms DP5_ME: build {1e3*(t1-t0):.1f} ms, run {1e3*(t2-t1):.1f} ms")
+pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
