@@ -49,6 +49,7 @@ constexpr int kLanePairMax = 3;
 
 struct LanePairs {
     int n;
+    unsigned dl[kLanePairMax];     // relative flips the block has at all (PairArgs.dl; uniform)
     int d[kLanePairMax][3];        // lane offsets D(1) = mb, D(2) = ma, D(3) = ma | mb
     double2 c[kLanePairMax][4];    // row of the block: c[t][delta] = T_t[4 * own + (delta ^ own)]
 
@@ -61,6 +62,7 @@ struct LanePairs {
             d[t][0] = int(mb);
             d[t][1] = int(ma);
             d[t][2] = int(ma | mb);
+            dl[t] = t < n ? pa.dl[t] : 0u;
 #pragma unroll
             for (int dl = 0; dl < 4; ++dl)
                 c[t][dl] = t < n ? pa.tab[(t * 2 + which) * 16 + own * 4 + (dl ^ own)] : make_double2(0.0, 0.0);
@@ -76,6 +78,7 @@ struct LanePairs {
                 acc.y += c[t][0].x * v.y + c[t][0].y * v.x;
 #pragma unroll
                 for (int dl = 1; dl < 4; ++dl) {
+                    if (!(this->dl[t] >> dl & 1u)) continue;  // uniform: this relative flip does not occur in the block
                     const int src = int(lane) ^ d[t][dl - 1];
                     const double qx = __shfl(v.x, src, 64), qy = __shfl(v.y, src, 64);
                     acc.x += c[t][dl].x * qx - c[t][dl].y * qy;

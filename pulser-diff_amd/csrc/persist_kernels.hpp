@@ -31,12 +31,13 @@ __device__ __forceinline__ double2 pair_apply_tile(const PairArgs& pa, int which
     for (int t = 0; t < pa.n; ++t) {
         const uint32_t ma = pa.ma[t], mb = pa.mb[t];
         const int own = ((x & ma) ? 2 : 0) | ((x & mb) ? 1 : 0);
-        const unsigned base = x & ~(ma | mb);
         const double2* row = stab + (t * 2 + which) * 16 + own * 4;
+        const unsigned dm = pa.dl[t];  // relative flips the block has at all (uniform): the others cost nothing
 #pragma unroll
-        for (int sidx = 0; sidx < 4; ++sidx) {
-            const double2 c = row[sidx];
-            const double2 q = tile[base | ((sidx & 2) ? ma : 0u) | ((sidx & 1) ? mb : 0u)];
+        for (int dlt = 0; dlt < 4; ++dlt) {
+            if (!(dm >> dlt & 1u)) continue;
+            const double2 c = row[own ^ dlt];
+            const double2 q = tile[x ^ ((dlt & 2) ? ma : 0u) ^ ((dlt & 1) ? mb : 0u)];
             acc.x += c.x * q.x - c.y * q.y;
             acc.y += c.x * q.y + c.y * q.x;
         }

@@ -87,6 +87,11 @@ struct PairArgs {
     const double2* tab = nullptr;  // [n][2][16]: forward table, then its conjugate transpose
     uint32_t ma[RYDIFF_MAX_PAIR_TERMS];
     uint32_t mb[RYDIFF_MAX_PAIR_TERMS];
+    // which relative flips delta = own ^ s the block of term t has at all (bit delta: some T[own][own ^ delta] != 0, in the block or its
+    // conjugate transpose; bit 0 = the diagonal, 1 = flip b, 2 = flip a, 3 = flip both).  Collapse operators populate few of them —
+    // dephasing (Z (x) Z) the diagonal only, relaxation / depolarizing the diagonal and the double flip — and the kernels skip the rest
+    // uniformly: no coefficient reads, no partner reads.
+    uint8_t dl[RYDIFF_MAX_PAIR_TERMS];
 };
 
 // sum_p sum_s T_p[4*own + s] * v[x with the pair's bits set to s];  which = 0: T, 1: T^dagger
@@ -95,13 +100,14 @@ __device__ __forceinline__ double2 pair_apply(const PairArgs& pa, int which, con
     for (int t = 0; t < pa.n; ++t) {
         const uint32_t ma = pa.ma[t], mb = pa.mb[t];
         const int own = ((x & ma) ? 2 : 0) | ((x & mb) ? 1 : 0);
-        const uint32_t base = x & ~(ma | mb);
         const double2* __restrict__ row = pa.tab + (size_t(t) * 2 + which) * 16 + own * 4;
+        const unsigned dm = pa.dl[t];
 #pragma unroll
-        for (int sidx = 0; sidx < 4; ++sidx) {
-            const double2 c = row[sidx];
+        for (int dlt = 0; dlt < 4; ++dlt) {
+            if (!(dm >> dlt & 1u)) continue;  // uniform
+            const double2 c = row[own ^ dlt];
             if (c.x == 0.0 && c.y == 0.0) continue;
-            const double2 q = v[base | ((sidx & 2) ? ma : 0u) | ((sidx & 1) ? mb : 0u)];
+            const double2 q = v[x ^ ((dlt & 2) ? ma : 0u) ^ ((dlt & 1) ? mb : 0u)];
             acc.x += c.x * q.x - c.y * q.y;
             acc.y += c.x * q.y + c.y * q.x;
         }
@@ -1164,6 +1170,14 @@ int finish_runtime(Runtime& rt, double lo, double hi) {
     for (int t = 0; t < pl.n_pair; ++t) {
         rt.parg.ma[t] = pl.pair_ma[t];
         rt.parg.mb[t] = pl.pair_mb[t];
+        unsigned dm = 0;  // relative flips present in the block or its conjugate transpose (PairArgs.dl)
+        for (int w = 0; w < 2; ++w)
+            for (int own = 0; own < 4; ++own)
+                for (int s = 0; s < 4; ++s) {
+                    const double* e = pl.pair_tab.data() + size_t(t) * 64 + size_t(w) * 32 + size_t(own * 4 + s) * 2;
+                    if (e[0] != 0.0 || e[1] != 0.0) dm |= 1u << (own ^ s);
+                }
+        rt.parg.dl[t] = uint8_t(dm);
     }
     return RYDIFF_OK;
 }

@@ -1,3 +1,5 @@
+"""End-to-end time of a master-equation emulator run (DP5_ME on the doubled register) with a cProfile of the host side:
+python tools/time_master_equation.py [atoms] [noise types, comma separated]"""
 import cProfile, gc, pstats, sys, time
 sys.path.insert(0, "/root/repo")
 import torch
@@ -9,7 +11,8 @@ reg = pl.Register.rectangle(1, n, spacing=8, prefix="q")
 seq = pl.Sequence(reg, pl.MockDevice)
 seq.declare_channel("g", "rydberg_global")
 seq.add(pl.Pulse(pl.BlackmanWaveform(500, 4.0), pl.RampWaveform(500, -3.0, 2.0), 0.0), "g")
-cfg = P.SimConfig(noise=("dephasing", "relaxation"), dephasing_rate=0.2, relaxation_rate=0.1)
+noise = tuple((sys.argv[2] if len(sys.argv) > 2 else "dephasing,relaxation").split(","))
+cfg = P.SimConfig(noise=noise, dephasing_rate=0.2, relaxation_rate=0.1, depolarizing_rate=0.05)
 gc.collect(); gc.freeze()
 for it in range(3):
     if it == 2:
@@ -21,5 +24,5 @@ for it in range(3):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     if it == 2: pr.disable()
-print(f"{n} atoms DP5_ME: build {1e3*(t1-t0):.1f} ms, run {1e3*(t2-t1):.1f} ms")
+print(f"{n} atoms DP5_ME {noise}: build {1e3*(t1-t0):.1f} ms, run {1e3*(t2-t1):.1f} ms")
 pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
