@@ -52,6 +52,8 @@ for case in range(n_cases):
         amp = amp.real.contiguous()
     tape = str(rng.choice(["auto", "steps", "full", "partial"]))  # partial: the last tape_steps save intervals taped (13 qubits and up; steps below)
     tape_steps = int(rng.integers(1, len(tsave0))) if tape == "partial" else None
+    if tape == "full" and n >= 22:
+        tape = "auto"  # an explicitly requested full tape is never downgraded: 24 qubits x a dozen DP5 stages per interval would be 300 GiB
     # three-level style problems (include/rydiff.h: amp_conditioned_terms / det_ones_terms): every amplitude term conditioned, the
     # detuning terms all ones-counting or all not (terms that share a qubit must agree); even registers, complex tables
     three = n % 2 == 0 and n >= 2 and not real_tables and rng.random() < 0.2
@@ -72,6 +74,9 @@ for case in range(n_cases):
         loss.backward()
         out[variant] = [expect.detach().cpu().numpy()] + [(l.grad if l.grad is not None else torch.zeros_like(l)).detach().cpu().numpy() for l in leaves]
         out[(variant, "stats")] = dict(spec.options["_last_stats"])
+        del states, expect, loss, leaves, w  # the workspace (tape) of this variant goes back before the next one plans its own
+        if n >= 20:
+            torch.cuda.empty_cache()
     _native.set_kernel_variant(0)
     errs = []
     for variant in variants[1:]:
