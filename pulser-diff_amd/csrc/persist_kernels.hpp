@@ -180,9 +180,25 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist(P
                     q[r].x = dr * v[r].x - di * v[r].y;
                     q[r].y = dr * v[r].y + di * v[r].x;
                 }
+                double2 sreal[R];  // !CPLX (phase-free drives): sum_b c_b * partner_b with REAL c_b, multiplied by beta once at the end
+#pragma unroll
+                for (int r = 0; r < R; ++r) sreal[r] = make_double2(0.0, 0.0);
                 auto flip_bit = [&](auto bc) {
                     constexpr int bb = decltype(bc)::value;
                     if (ga_of[bb] < 0) return;  // uniform
+                    if constexpr (!CPLX) {  // 2 FMAs per partner instead of 4, no per-lane coefficient choice
+                        const double cr = cpb[ga_of[bb]];
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            double2 pv;
+                            if constexpr (bb >= LGT) pv = v[r ^ (1 << (bb >= LGT ? bb - LGT : 0))];
+                            else if constexpr (LT <= 6) pv = lanes ? lane_xor<(bb < 6 ? bb : 0)>(v[r]) : tile[(unsigned(r) * NT + tid) ^ (1u << bb)];
+                            else pv = tile[(unsigned(r) * NT + tid) ^ (1u << bb)];
+                            sreal[r].x = fma(cr, pv.x, sreal[r].x);
+                            sreal[r].y = fma(cr, pv.y, sreal[r].y);
+                        }
+                        return;
+                    }
                     const double cr = cpb[ga_of[bb]], ci = cpb[a.ga + ga_of[bb]];
                     const double k1r = pf.br * cr - pf.bi * ci, k1i = pf.br * ci + pf.bi * cr;  // beta c       (own bit set)
                     const double k0r = pf.br * cr + pf.bi * ci, k0i = pf.bi * cr - pf.br * ci;  // beta conj(c) (own bit clear)
@@ -204,6 +220,13 @@ __global__ __launch_bounds__((1 << LGT) < 64 ? 64 : (1 << LGT)) void k_persist(P
                     }
                 };
                 static_for<0, LT>(flip_bit);
+                if constexpr (!CPLX) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        q[r].x += pf.br * sreal[r].x - pf.bi * sreal[r].y;
+                        q[r].y += pf.br * sreal[r].y + pf.bi * sreal[r].x;
+                    }
+                }
             }
         } else if (active) {
             double dsh[R];  // time-dependent part of the diagonal

@@ -1932,7 +1932,7 @@ int launch_persist_t(const PersistArgs& pa, int B, hipStream_t stream) {
     constexpr int LGT = LT < 10 ? LT : 10;
     const dim3 block(LGT < 6 ? 64 : (1 << LGT));
     if (per_bit_terms(pa) && pa.NC <= 3 * LT)
-        hipLaunchKernelGGL((k_persist<LT, LGT, true, false, false, kPersistGroups, true>), dim3(B), block, 0, stream, pa);
+        hipLaunchKernelGGL((k_persist<LT, LGT, CPLX, false, false, kPersistGroups, true>), dim3(B), block, 0, stream, pa);
     else if (pa.ga == 1 && pa.gd <= 1 && pa.amask[0] == (1u << LT) - 1u && pa.pair.n == 0 && pa.cond == 0)
         hipLaunchKernelGGL((k_persist<LT, LGT, CPLX, true, true>), dim3(B), block, 0, stream, pa);
     else if (pa.ga <= 2 && pa.gd <= 2)

@@ -329,10 +329,11 @@ def test_global_drive_with_local_detuning_channels_on_the_loop_free_chained_kern
         assert rel_err(got.numpy(), ref.numpy()) < 1e-9, name
 
 
+@pytest.mark.parametrize("phase", [True, False])  # False: phase-free drives (real coefficients: the 2-FMA form of the per-bit sweep)
 @pytest.mark.parametrize("n_qubits,batch,solver_name,grads", [(5, 4, "KRYLOV_SE", True), (6, 3, "DP5_SE", True), (7, 5, "KRYLOV_SE", False),
                                                             (8, 3, "KRYLOV_SE", True), (10, 2, "DP5_SE", False), (11, 2, "KRYLOV_SE", True),
                                                             (12, 2, "KRYLOV_SE", True)])
-def test_per_atom_terms_on_the_one_workgroup_sweep_match_direct_kernels(cuda_device, n_qubits, batch, solver_name, grads):
+def test_per_atom_terms_on_the_one_workgroup_sweep_match_direct_kernels(cuda_device, n_qubits, batch, solver_name, grads, phase):
     """ONE single-qubit amplitude term and ONE single-qubit detuning term per atom with per-trajectory tables — what the stochastic-noise
     runs hand over (backend._run_noisy; from 7 qubits on all but one atom driven and all but another detuned) — on the per-bit form of the one-workgroup
     forward sweep (k_persist<..., PERBIT>) against the direct kernels: every stored state, <O>(t_k) and, where asked, every gradient
@@ -346,7 +347,8 @@ def test_per_atom_terms_on_the_one_workgroup_sweep_match_direct_kernels(cuda_dev
     amp_q = [q for q in range(n_qubits) if q != 1 or n_qubits < 7]  # (5 / 6 qubits: every atom, so that there are more than 4 groups)
     det_q = [q for q in range(n_qubits) if q != n_qubits - 1 or n_qubits < 7]
     amp = (0.5 * 7.0 * torch.sin(torch.pi * t) ** 2)[None, None] * (1.0 + 0.2 * torch.randn(batch, len(amp_q), 1, generator=gen, dtype=torch.float64))
-    amp = (amp * torch.exp(-1j * (0.5 * t + 0.3 * torch.rand(batch, len(amp_q), 1, generator=gen, dtype=torch.float64)))).to(torch.complex128).to(cuda_device)
+    ph = (0.5 * t + 0.3 * torch.rand(batch, len(amp_q), 1, generator=gen, dtype=torch.float64)) if phase else torch.zeros(batch, len(amp_q), 9, dtype=torch.float64)
+    amp = (amp * torch.exp(-1j * ph)).to(torch.complex128).to(cuda_device)
     det = ((-0.5 * (-4.0 + 8.0 * t))[None, None] + 0.7 * torch.randn(batch, len(det_q), 1, generator=gen, dtype=torch.float64)).to(cuda_device).contiguous()
     coords = torch.stack([torch.arange(n_qubits, dtype=torch.float64) * 7.5, torch.rand(n_qubits, generator=gen, dtype=torch.float64)], 1)
     u = R.interaction_strengths(coords).to(cuda_device)
