@@ -122,6 +122,7 @@ class Hamiltonian:
     # level names of every basis, in the order that fixes the amplitude index (hamiltonian.py:288-318): level 0 is the one the
     # detuning projector sits on, the drive lowers level 0 -> level 1 (c |1><0| + h.c., hamiltonian.py:410-416)
     _LEVELS = {"XY": ("u", "d"), "ground-rydberg": ("r", "g"), "digital": ("g", "h"), "all": ("r", "g", "h")}
+    ROTATING_FRAME = True  # evolve sequences with ONE constant drive phase in the frame that rotates with it (see _construct_hamiltonian)
 
     def _select_basis(self) -> None:
         """Which levels the register has.  The three two-level bases share one structure (a lowering operator driven by
@@ -361,6 +362,8 @@ class Hamiltonian:
 
         phase_free = [True]  # every drive has phase 0 and no gradient is asked for the phase
         three = self.basis_name == "all"
+        frame_phases: list = []    # per amplitude term: its phase where it drives, if that is ONE value (else None) — see frame_phase below
+        frame_rows: list = []      # per amplitude term: 0.5 * amp, the drive in the frame that rotates with that phase
 
         def add_terms(samples: dict, atoms: list, basis: str) -> None:
             # hamiltonian.py:420-433 / 439-452
@@ -374,6 +377,11 @@ class Hamiltonian:
                 mask = sum(1 << j for j in atoms)
                 if has_amp:
                     amp_terms.append((self._adapt_to_sampling_rate(amp_c), mask))
+                    on = ph[samples["amp"] != 0]
+                    # (a phase that carries a gradient is left alone: equal VALUES may still be different leaves — eight pulses whose
+                    # phases all start at 5.0 — and the frame would hand every sample's gradient to one of them)
+                    frame_phases.append(on[0].detach() if (not ph.requires_grad and bool(torch.all(on == on[0]))) else None)
+                    frame_rows.append(self._adapt_to_sampling_rate(0.5 * samples["amp"]))
                 if has_det:
                     det_terms.append((self._adapt_to_sampling_rate(det_c), mask))
                 return
@@ -425,6 +433,17 @@ class Hamiltonian:
         # real-valued drives: the solver is handed the REAL part of the tables, so that autograd only asks for dL/dRe(amp)
         # and the native adjoint skips the dL/dIm(amp) contractions (RydProblem.real_amp_grad)
         self.amp_is_real = bool(amp_terms) and phase_free[0]
+        # ONE constant drive phase without a gradient (a sequence whose pulses all carry the same fixed phase): in the frame that rotates with it,
+        # V = exp(i phi sum_j |1><1|_j), the drive c |1><0| + h.c. = 0.5 amp e^{-i phi} |1><0| + h.c. becomes the REAL 0.5 amp (|1><0| + h.c.)
+        # and the diagonal terms do not change.  solver.sesolve then evolves V psi0 with real tables — the loop-free kernels without signed
+        # partner sums, and the single-tape-read adjoint (3R+2W instead of 4R+2W on the chained tiles) — and turns the states back.
+        # Exact (a unitary change of frame), per call.
+        self.frame_phase = None
+        self.amp_tables_frame = None
+        if (self.ROTATING_FRAME and amp_terms and not three and not self.amp_is_real and self._interaction != "XY"
+                and all(p is not None for p in frame_phases) and all(bool(p == frame_phases[0]) for p in frame_phases)):
+            self.frame_phase = frame_phases[0]
+            self.amp_tables_frame = torch.stack(frame_rows).unsqueeze(0).to(dev)
         self.piece_refine = self._piece_refinement(amp_terms, det_terms)
         self._hamiltonian = self.build_ham_tensor()
 

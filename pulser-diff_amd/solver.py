@@ -415,7 +415,21 @@ def sesolve(problem, psi0: Tensor, tsave: Tensor, solver: SolverType = SolverTyp
         if obs_diag is not None:
             obs_diag = torch.zeros(obs_diag.shape[0], 1 << spec.n_qubits, dtype=obs_diag.dtype,
                                    device=obs_diag.device).index_copy(1, embed, obs_diag)
+    rot = None
+    phi = getattr(problem, "frame_phase", None)
+    if phi is not None and embed is None and not spec.pair_terms:
+        # one constant drive phase: evolve in the frame that rotates with it (hamiltonian.py: frame_phase) — real tables, V psi0 in,
+        # V^dagger psi(t) out; diagonal observables do not see the frame
+        amp_tables = problem.amp_tables_frame
+        x = torch.arange(1 << spec.n_qubits, device=psi_bd.device)
+        ones = torch.zeros(1 << spec.n_qubits, dtype=torch.float64, device=psi_bd.device)
+        for j in range(spec.n_qubits):
+            ones += ((x >> j) & 1).to(torch.float64)
+        rot = torch.exp(1j * float(phi) * ones)
+        psi_bd = psi_bd * rot[None, :]
     states, expect = evolve(amp_tables, problem.det_tables, problem.u_pairs, tsave, psi_bd, spec, obs_diag)
+    if rot is not None and states.numel():
+        states = states * rot.conj()[None, None, :]
     if embed is not None and states.numel():
         states = states.index_select(2, embed)
     return SolveResult(states.permute(0, 2, 1) if states.numel() else states, expect,

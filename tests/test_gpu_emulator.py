@@ -121,6 +121,64 @@ def test_deriv_param_and_deriv_time_against_oracle_autograd(cuda_device):
     assert np.abs(g_t.detach().cpu().numpy() - ref_t.numpy()).max() < 1e-8 * float(ref_t.abs().max())
 
 
+@pytest.mark.parametrize("n_atoms,solver_name", [(3, "KRYLOV_SE"), (6, "DP5_SE"), (9, "KRYLOV_SE"), (14, "KRYLOV_SE"), (20, "KRYLOV_SE")])
+def test_one_constant_drive_phase_runs_in_the_rotating_frame(cuda_device, n_atoms, solver_name):
+    """A sequence whose pulses all carry ONE fixed phase (here on a global and a local channel) is evolved in the frame that rotates with
+    it: real coefficient tables (the loop-free kernels without signed sums, the single-tape-read adjoint on the chained tiles), V psi0 in
+    and V^dagger psi(t) out.  Against the same run with the frame switched off (complex tables: the path the oracle tests pin) on every
+    kernel family — states at every evaluation time, <sum Z>(t), and the gradients w.r.t. an amplitude and a detuning parameter; at 3
+    atoms also against the oracle directly.  A phase that carries a gradient keeps the complex tables (equal values may be different
+    leaves: the eight pulses of the constant-pulse gate notebook all start at phase 5.0)."""
+    from pulser_diff_amd.hamiltonian import Hamiltonian
+
+    def run(frame):
+        omega = torch.tensor(4.0, dtype=torch.float64, requires_grad=True)
+        slope = torch.tensor(2.0, dtype=torch.float64, requires_grad=True)
+        phase = torch.tensor(0.7, dtype=torch.float64)
+        reg = pl.Register.rectangle(2 if n_atoms % 2 == 0 else 1, n_atoms // 2 if n_atoms % 2 == 0 else n_atoms, spacing=7.5, prefix="q")
+        seq = pl.Sequence(reg, pl.MockDevice)
+        seq.declare_channel("g", "rydberg_global")
+        seq.declare_channel("l", "rydberg_local", initial_target="q1")
+        seq.add(pl.Pulse(pl.BlackmanWaveform(60, omega * 0.5), pl.RampWaveform(60, -3.0, slope), phase), "g")
+        seq.add(pl.Pulse(pl.RampWaveform(40, 0.0, 5.0), pl.ConstantWaveform(40, -1.5), phase), "l")
+        old = Hamiltonian.ROTATING_FRAME
+        Hamiltonian.ROTATING_FRAME = frame
+        try:
+            sim = P.TorchEmulator.from_sequence(seq, evaluation_times=0.2)
+            assert (sim._hamiltonian.frame_phase is not None) == frame
+            res = sim.run(solver=SolverType[solver_name])
+        finally:
+            Hamiltonian.ROTATING_FRAME = old
+        z = res.expect([DiagonalObservable(total_magnetization_diag(n_atoms))])[0].real
+        probe = torch.linspace(0.2, 1.0, 2**n_atoms, dtype=torch.float64, device=res.states.device)
+        loss = (z * torch.linspace(0.5, 1.5, len(z), dtype=torch.float64, device=z.device)).sum() + (res.states[-1, :, 0].real * probe).sum()
+        g = torch.autograd.grad(loss, [omega, slope])
+        return res.states.detach(), z.detach(), [t.detach().cpu() for t in g], sim
+
+    s_on, z_on, g_on, sim = run(True)
+    s_off, z_off, g_off, _ = run(False)
+    assert float((s_on - s_off).abs().max()) < 1e-10
+    assert float((z_on - z_off).abs().max()) < 1e-10
+    for name, a, b in zip(("omega", "slope"), g_on, g_off):
+        assert abs(float(a) - float(b)) < 1e-8 * max(1.0, abs(float(b))), name
+    if n_atoms == 3:  # a trainable phase is not touched
+        ph = torch.tensor(0.7, dtype=torch.float64, requires_grad=True)
+        seq = pl.Sequence(pl.Register.rectangle(1, 3, spacing=7.5, prefix="q"), pl.MockDevice)
+        seq.declare_channel("g", "rydberg_global")
+        seq.add(pl.Pulse.ConstantPulse(40, 3.0, 1.0, ph), "g")
+        assert P.TorchEmulator.from_sequence(seq)._hamiltonian.frame_phase is None
+    if n_atoms == 3:  # the oracle, from the pulses' definitions
+        coords = torch.stack([sim._hamiltonian._qdict[q] for q in sim._hamiltonian._qdict]).to(torch.float64).cpu()
+        terms = R.build_terms(R.concat_pulses([(R.blackman_waveform(60, 2.0), R.ramp_waveform(60, -3.0, 2.0), 0.7)]), coords, 1.0)
+        z20 = torch.zeros(21, dtype=torch.float64)
+        lamp = torch.cat([R.ramp_waveform(40, 0.0, 5.0), z20])
+        ldet = torch.cat([R.constant_waveform(40, -1.5), z20])
+        terms.extra_amp = [(0.5 * lamp * torch.exp(-1j * torch.full((61,), 0.7, dtype=torch.complex128)), [1])]
+        terms.extra_det = [(-0.5 * ldet, [1])]
+        ref = R.krylov_map_dense(terms, R.all_ground_state(3), sim.evaluation_times.detach().cpu())
+        assert float((s_on.cpu() - ref).abs().max()) < 1e-10
+
+
 def test_local_channel_sequence_and_batched_initial_states(cuda_device):
     reg = pl.Register.rectangle(1, 3, spacing=7)
     seq = pl.Sequence(reg, pl.MockDevice)
